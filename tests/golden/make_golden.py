@@ -1,0 +1,138 @@
+#!/usr/bin/env python3
+"""Mint golden vectors from the REFERENCE implementation (build container only).
+
+Imports /root/reference/CALM-ViT/{Vi_Tools_CNN_less_V2,CALM_ViT_V2}.py (torchvision, which the
+image lacks and only the reference's dataset/__main__ code touches, is stubbed in sys.modules),
+fills it with numpy-seeded weights (tests/golden/weights.py), runs 5 train() warm-up forwards so
+the spectral-norm u,v converge (fresh-init eval() output is NaN), then records
+eval and train forward/backward results.  Only DATA is written: name->shape inventories (json)
+and tensors (npz).  Run:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import weights as W  # noqa: E402
+
+REF = "/root/reference/CALM-ViT"
+
+CONFIGS = {
+    # SURVEY.md 8(d) variant table
+    "nano48_cls": dict(heads=3, seq_length=48, in_features=144, dim_step=12, mean_var_hidden=24,
+                       seq_len_step=4, seq_len_reduce=16, out_features=10, force_reduce=False, generate=False),
+    "nano48_gen": dict(heads=3, seq_length=48, in_features=144, dim_step=12, mean_var_hidden=24,
+                       seq_len_step=4, seq_len_reduce=16, out_features=10, force_reduce=False, generate=True),
+    "tiny32_cls": dict(heads=4, seq_length=32, in_features=96, dim_step=0, mean_var_hidden=24,
+                       seq_len_step=0, seq_len_reduce=16, out_features=10, force_reduce=False, generate=False),
+    "tiny32_fr": dict(heads=4, seq_length=32, in_features=96, dim_step=0, mean_var_hidden=24,
+                      seq_len_step=0, seq_len_reduce=16, out_features=10, force_reduce=True, generate=False),
+}
+INVENTORY_ONLY = {
+    "small224_cls": dict(heads=6, seq_length=224, in_features=672, dim_step=48, mean_var_hidden=120,
+                         seq_len_step=16, seq_len_reduce=40, out_features=1000, force_reduce=False, generate=False),
+    "base224_cls": dict(heads=12, seq_length=224, in_features=672, dim_step=48, mean_var_hidden=240,
+                        seq_len_step=16, seq_len_reduce=80, out_features=1000, force_reduce=False, generate=False),
+}
+BATCH = 2
+WEIGHT_SEED = 1234
+FULL_GRAD_PREFIXES = ("autoencoder.encoder_blocks.0.encoder.", "autoencoder.encoder_blocks.0.cross.",
+                      "autoencoder.encoder_blocks.0.proj.", "autoencoder.decoder_blocks.2.cross.",
+                      "autoencoder.ln_final.", "head.", "proj.")
+
+
+def import_reference():
+    for m in ("torchvision", "torchvision.transforms", "torchvision.transforms.v2", "torchvision.datasets",
+              "torchvision.transforms.functional", "torchvision.models"):
+        sys.modules.setdefault(m, MagicMock())
+    sys.path.insert(0, REF)
+    import CALM_ViT_V2 as rvh
+    return rvh
+
+
+def run_with_noise(fn, seed):
+    orig = torch.randn_like
+    torch.randn_like = W.NoiseStream(seed)
+    try:
+        return fn()
+    finally:
+        torch.randn_like = orig
+
+
+def kl_value(kl):
+    return np.float32(kl.item() if torch.is_tensor(kl) else kl)
+
+
+def mint(name, kw, rvh):
+    model = rvh.ViT(torch.device("cpu"), type=8, **kw)
+    sd = model.state_dict()
+    shapes = {k: list(v.shape) for k, v in sd.items()}
+    with open(os.path.join(HERE, f"state_dict_{name}.json"), "w") as f:
+        json.dump(shapes, f, indent=0, sort_keys=True)
+    params = W.make_params(shapes, WEIGHT_SEED)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()}, strict=True)
+    S = kw["seq_length"]
+    out = {}
+    # 1. warm-up: 5 train forwards
+    xw = torch.from_numpy(W.make_input((BATCH, 3, S, S), 1))
+    model.train()
+    for i in range(5):
+        with torch.no_grad():
+            run_with_noise(lambda: model(xw), 100 + i)
+    sd = model.state_dict()
+    for k, v in sd.items():
+        if k.endswith(("weight_u", "weight_v")):
+            out["warm/" + k] = v.detach().numpy().copy()
+    # 2. eval forward
+    x = torch.from_numpy(W.make_input((BATCH, 3, S, S), 2)).requires_grad_(True)
+    model.eval()
+    with torch.no_grad():
+        y, kl = model(x)
+    out["eval/y"] = y.numpy().copy()
+    out["eval/kl"] = kl_value(kl)
+    # 3. train forward + backward
+    model.train()
+    y, kl = run_with_noise(lambda: model(x), 7)
+    gy = torch.from_numpy(W.make_input(tuple(y.shape), 3, "gy"))
+    loss = (y * gy).sum() + 0.5 * kl
+    loss.backward()
+    out["train/y"] = y.detach().numpy().copy()
+    out["train/kl"] = kl_value(kl)
+    out["train/loss"] = np.float32(loss.item())
+    out["train/dx"] = x.grad.numpy().copy()
+    names, norms = [], []
+    for k, p in model.named_parameters():
+        names.append(k)
+        norms.append(float(p.grad.norm()) if p.grad is not None else -1.0)
+        if k.startswith(FULL_GRAD_PREFIXES):
+            out["grad/" + k] = p.grad.numpy().copy()
+    out["train/grad_names"] = np.array(names)
+    out["train/grad_norms"] = np.array(norms, dtype=np.float32)
+    for k, v in model.state_dict().items():
+        if k.endswith(("weight_u", "weight_v")) and k.startswith(FULL_GRAD_PREFIXES):
+            out["post/" + k] = v.detach().numpy().copy()
+    np.savez_compressed(os.path.join(HERE, f"golden_{name}.npz"), **out)
+    print(name, "params", sum(int(np.prod(s)) for k, s in shapes.items()), "loss", out["train/loss"],
+          "kl", out["train/kl"], "|y|max", float(np.abs(out["eval/y"]).max()))
+
+
+def main():
+    torch.set_num_threads(4)
+    rvh = import_reference()
+    for name, kw in CONFIGS.items():
+        mint(name, kw, rvh)
+    for name, kw in INVENTORY_ONLY.items():
+        model = rvh.ViT(torch.device("cpu"), type=8, **kw)
+        shapes = {k: list(v.shape) for k, v in model.state_dict().items()}
+        with open(os.path.join(HERE, f"state_dict_{name}.json"), "w") as f:
+            json.dump(shapes, f, indent=0, sort_keys=True)
+        print(name, "entries", len(shapes))
+
+
+if __name__ == "__main__":
+    main()

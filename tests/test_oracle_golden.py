@@ -1,0 +1,56 @@
+"""The CPU oracle (oracle/calm_oracle.py) against fixtures minted from the imported reference
+(tests/golden/make_golden.py).  Tolerance 1e-5 relative (max-abs / max-abs), fp32."""
+import numpy as np
+import pytest
+import torch
+
+import weights as W
+from helpers import CONFIGS, load_golden, load_inventory, oracle_params, rel_err
+from oracle import calm_oracle as O
+
+TOL = 1e-5
+GOLDEN_CFGS = ["nano48_cls", "nano48_gen", "tiny32_cls", "tiny32_fr"]
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_param_inventory_matches_reference_state_dict(name):
+    assert O.vit_param_shapes(CONFIGS[name]) == load_inventory(name)
+
+
+@pytest.mark.parametrize("name", GOLDEN_CFGS)
+def test_eval_forward(name):
+    g = load_golden(name)
+    cfg = CONFIGS[name]
+    P = oracle_params(name, g, requires_grad=False)
+    x = torch.from_numpy(W.make_input((2, 3, cfg.seq_length, cfg.seq_length), 2))
+    with torch.no_grad():
+        y, kl = O.vit_forward(P, cfg, x, training=False)
+    assert rel_err(y, g["eval/y"]) < TOL
+    assert abs(float(kl) - float(g["eval/kl"])) <= TOL * max(1.0, abs(float(g["eval/kl"])))
+    if name == "tiny32_cls":
+        assert isinstance(kl, float) and kl == 0.0          # Vi_Tools:49-50 python 0.0
+
+
+@pytest.mark.parametrize("name", GOLDEN_CFGS)
+def test_train_forward_backward(name):
+    g = load_golden(name)
+    cfg = CONFIGS[name]
+    P = oracle_params(name, g)
+    x = torch.from_numpy(W.make_input((2, 3, cfg.seq_length, cfg.seq_length), 2)).requires_grad_(True)
+    y, kl = O.vit_forward(P, cfg, x, training=True, noise=W.NoiseStream(7))
+    gy = torch.from_numpy(W.make_input(tuple(y.shape), 3, "gy"))
+    loss = (y * gy).sum() + 0.5 * kl
+    loss.backward()
+    assert rel_err(y.detach(), g["train/y"]) < TOL
+    assert abs(float(kl) - float(g["train/kl"])) < TOL * max(1.0, abs(float(g["train/kl"])))
+    assert rel_err(x.grad, g["train/dx"]) < 5 * TOL
+    names = [str(n) for n in g["train/grad_names"]]
+    norms = g["train/grad_norms"]
+    for n, ref in zip(names, norms):
+        got = float(P[n].grad.norm())
+        assert abs(got - ref) <= 2e-4 * max(abs(ref), 1e-6) + 1e-9, (n, got, ref)
+    for key in g.files:
+        if key.startswith("grad/"):
+            assert rel_err(P[key[5:]].grad, g[key]) < 5 * TOL, key
+        if key.startswith("post/"):                         # in-place power-iteration result
+            assert rel_err(P[key[5:]], g[key]) < TOL, key
