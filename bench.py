@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec of the CALM-ViT path on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one training iteration of distributed_trainer_cls.py:79-96 on one synthetic batch that is
+already resident in HBM: forward, soft-target cross-entropy, backward (+ gradient all-reduce when N>1),
+clip_grad_norm_(1.0), AdamW, zero_grad.  Workload at N=1: BASELINE.json configs[1] — CALM-ViT-Small,
+224x224, bs=256/GPU, fp32 (SURVEY.md 8(d) variant table).  Weak scaling: every rank keeps bs/GPU.
+
+Rank 0 prints ONE JSON line.  Besides the driver's contract it carries
+  "roofline":     the dominant kernel (the fp32 MFMA GEMM family, calm_gemm): algorithmic FLOPs of the
+                  calls of `prof_steps` steps / their summed durations measured with HIP events on the
+                  launch stream, against the dense fp32-matrix peak (157.3 TFLOP/s).
+  "cpu_baseline": the CPU oracle (oracle/calm_oracle.py, a port; the reference's Python cannot travel)
+                  timed on this host on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    # kwargs of ViT(...); fwd+bwd GFLOP/img measured on the reference
+    "small224": dict(kw=dict(heads=6, seq_length=224, in_features=672, dim_step=48, mean_var_hidden=120,
+                             seq_len_step=16, seq_len_reduce=40, out_features=1000), gflop_img=46.063, batch=256),
+    "base224": dict(kw=dict(heads=12, seq_length=224, in_features=672, dim_step=48, mean_var_hidden=240,
+                            seq_len_step=16, seq_len_reduce=80, out_features=1000), gflop_img=48.359, batch=256),
+    "nano48": dict(kw=dict(heads=3, seq_length=48, in_features=144, dim_step=12, mean_var_hidden=24,
+                           seq_len_step=4, seq_len_reduce=16, out_features=10), gflop_img=0.500, batch=64),
+}
+PEAK_FP32_MATRIX_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+WEIGHT_SEED = 1234
+
+
+def synthetic_batch(batch, S, classes, seed, device):
+    g = np.random.default_rng(seed)
+    x = torch.from_numpy(g.standard_normal((batch, 3, S, S)).astype(np.float32))
+    # MixUp-style soft labels: lam * onehot(a) + (1-lam) * onehot(b), lam ~ Beta(0.8, 0.8) (cls:58-61)
+    a, b = g.integers(0, classes, batch), g.integers(0, classes, batch)
+    lam = g.beta(0.8, 0.8)
+    y = np.zeros((batch, classes), dtype=np.float32)
+    y[np.arange(batch), a] += lam
+    y[np.arange(batch), b] += 1.0 - lam
+    return x.to(device), torch.from_numpy(y).to(device)
+
+
+def build_model(calm, kw, device):
+    import weights as W
+    m = calm.ViT(torch.device("cpu"), type=8, force_reduce=False, generate=False, **kw)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_params(shapes, WEIGHT_SEED).items()})
+    return m.to(device)
+
+
+class GemmProfiler:
+    """Wraps backend.gemm with HIP events on the launch stream (torch's current stream, which is the
+    stream every kernel of the library is enqueued on)."""
+
+    def __init__(self, be):
+        self.be = be
+        self.orig = be.gemm
+        self.records = []
+
+    def __enter__(self):
+        def gemm(A, B, C, M, N, K, a, b, c, batch=(1, 1), **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.orig(A, B, C, M, N, K, a, b, c, batch=batch, **kw)
+            e1.record()
+            self.records.append((2.0 * M * N * K * batch[0] * batch[1], e0, e1))
+        self.be.gemm = gemm
+        return self
+
+    def __exit__(self, *exc):
+        self.be.gemm = self.orig
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        flops = sum(r[0] for r in self.records)
+        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
+        return flops, ms, len(self.records)
+
+
+def cpu_baseline(wl, budget_s=25.0):
+    """CPU oracle (port of the reference path) fwd+bwd+AdamW on a bounded sample of the workload."""
+    from oracle import calm_oracle as O
+    import weights as W
+    threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    torch.set_num_threads(threads)
+    cfg = O.ViTConfig(force_reduce=False, generate=False, **wl["kw"])
+    P = {k: torch.from_numpy(v) for k, v in W.make_params(O.vit_param_shapes(cfg), WEIGHT_SEED).items()}
+    leaves = []
+    for k in P:
+        if not O.is_buffer(k):
+            P[k].requires_grad_(True)
+            leaves.append(P[k])
+    opt = torch.optim.AdamW(leaves, lr=3.1e-3, weight_decay=0.02, betas=(0.9, 0.98))
+    bs = 4 if cfg.seq_length >= 128 else 32
+    x, y = synthetic_batch(bs, cfg.seq_length, cfg.out_features, 0, "cpu")
+
+    def step():
+        out, _ = O.vit_forward(P, cfg, x, True)
+        loss = torch.nn.functional.cross_entropy(out, y)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(leaves, 1.0)
+        opt.step()
+        opt.zero_grad()
+
+    step()                                           # warm-up (also converges nothing: timing only)
+    times, t_start = [], time.perf_counter()
+    while len(times) < 5 and (time.perf_counter() - t_start) < budget_s:
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    return {"value": round(bs / med, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"oracle fwd+bwd+AdamW fp32, bs={bs}, {len(times)} timed steps after 1 warm-up, median"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="small224", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--prof-steps", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import calm_vit_dte_amd as calm
+    from importlib import import_module
+    trainer = import_module("calm_vit_dte_amd.trainer")
+
+    rank, local_rank, world = trainer.init_distributed(use_gpu=True)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    wl = WORKLOADS[args.workload]
+    batch = args.batch or wl["batch"]
+    S, classes = wl["kw"]["seq_length"], wl["kw"]["out_features"]
+
+    model = build_model(calm, wl["kw"], device).train()
+    trainer.sync_module_states(model)
+    opt = trainer.make_optimizer(model)
+    reducer = trainer.BucketedGradReducer(model) if world > 1 else None
+    step = trainer.TrainStep(model, opt, reducer)
+    x, y = synthetic_batch(batch, S, classes, seed=rank, device=device)     # resident in HBM before timing
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(x, y)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = step(x, y)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = 1e3 * dt / args.steps
+    value = world * batch * args.steps / dt
+
+    # dominant-kernel roofline: HIP events around every calm_gemm launch of prof_steps extra steps
+    roofline = None
+    if rank == 0 and args.prof_steps > 0:
+        with GemmProfiler(calm.backend.get_backend()) as prof:
+            for _ in range(args.prof_steps):
+                step(x, y)
+            flops, ms, n = prof.summary()
+        achieved = flops / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel (calm_gemm, v_mfma_f32_32x32x2_f32)",
+                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": n // args.prof_steps, "avg_launch_us": round(1e3 * ms / n, 2),
+                    "gemm_ms_per_step": round(ms / args.prof_steps, 2),
+                    "algorithmic_gflop_per_step": round(flops / args.prof_steps / 1e9, 1)}
+    if world > 1:
+        dist.barrier()
+
+    if rank == 0:
+        out = {
+            "metric": "training images/sec (224^2, bs=256/GPU)", "value": round(value, 2), "unit": "images/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"CALM-ViT {args.workload} cls, {S}x{S}x3 synthetic, bs={batch}/GPU, fp32, "
+                                   "fwd+loss+bwd+clip+AdamW", "global_batch": world * batch,
+                       "parallelism": f"dp{world}", "loss": float(loss)},
+            "model_tflops": round(value * wl["gflop_img"] / 1e3, 2),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,104 @@
+"""ctypes binding of libcalmvit_hip.so (the C-ABI declared in include/calm_vit.h).
+
+There is NO fallback: if the shared object is missing or a symbol cannot be resolved, loading
+raises and every op of the package fails loudly.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libcalmvit_hip.so")
+
+ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
+F32 = 0
+
+_p = C.c_void_p
+_i32 = C.c_int32
+_i64 = C.c_int64
+_f32 = C.c_float
+
+
+class GemmArgs(C.Structure):
+    """struct calm_gemm_args (include/calm_vit.h)."""
+    _fields_ = [
+        ("A", _p), ("B", _p), ("C", _p),
+        ("M", _i32), ("N", _i32), ("K", _i32),
+        ("batch0", _i32), ("batch1", _i32),
+        ("a_rs", _i64), ("a_cs", _i64), ("a_b0", _i64), ("a_b1", _i64),
+        ("b_rs", _i64), ("b_cs", _i64), ("b_b0", _i64), ("b_b1", _i64),
+        ("c_rs", _i64), ("c_b0", _i64), ("c_b1", _i64),
+        ("alpha", _f32),
+        ("inv_scale", _p), ("bias", _p), ("col_scale", _p),
+        ("residual", _p), ("r_rs", _i64), ("r_b0", _i64), ("r_b1", _i64),
+        ("C_pre", _p), ("aux", _p),
+        ("act", _i32), ("accumulate", _i32), ("reduce_batch", _i32), ("split_k", _i32), ("dtype", _i32),
+    ]
+
+
+class SnLayer(C.Structure):
+    """struct calm_sn_layer."""
+    _fields_ = [("w", _p), ("u", _p), ("v", _p), ("sigma", _p), ("rows", _i32), ("cols", _i32)]
+
+
+class SnPlanInfo(C.Structure):
+    """struct calm_sn_plan_info."""
+    _fields_ = [("blob_bytes", _i64), ("scratch_floats", _i64), ("n_layers", _i32), ("n_work", _i32)]
+
+
+# name -> (restype, argtypes); every symbol include/calm_vit.h declares
+SIGNATURES = {
+    "calm_abi_version": (_i32, []),
+    "calm_build_info": (C.c_char_p, []),
+    "calm_gemm": (_i32, [C.POINTER(GemmArgs), _p]),
+    "calm_layernorm_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _f32, _p]),
+    "calm_layernorm_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
+    "calm_rope_fwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "calm_rope_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "calm_softmax_fwd": (_i32, [_p, _i64, _i32, _p]),
+    "calm_softmax_bwd": (_i32, [_p, _p, _i64, _i32, _p]),
+    "calm_sum_heads": (_i32, [_p, _p, _i32, _i32, _i64, _p]),
+    "calm_latent_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _p]),
+    "calm_latent_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
+    "calm_sn_plan": (_i32, [C.POINTER(SnLayer), _i32, _p, C.POINTER(SnPlanInfo)]),
+    "calm_sn_power_iter": (_i32, [_p, C.POINTER(SnPlanInfo), _i32, _f32, _p, _p]),
+    "calm_sn_weight_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p, _p]),
+    "calm_image_to_rows": (_i32, [_p, _p, _i32, _i32, _p]),
+    "calm_rows_to_image": (_i32, [_p, _p, _i32, _i32, _p]),
+    "calm_grid_transpose": (_i32, [_p, _p, _i32, _i32, _p]),
+    "calm_dwconv3x3_fwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
+    "calm_dwconv3x3_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "calm_add": (_i32, [_p, _p, _p, _i64, _p]),
+    "calm_gelu_bwd": (_i32, [_p, _p, _p, _i64, _p]),
+    "calm_colsum": (_i32, [_p, _p, _i64, _i32, _p]),
+    "calm_row_scale": (_i32, [_p, _p, _p, _i32, _i32, _p]),
+    "calm_mean_seq_fwd": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
+    "calm_mean_seq_bwd": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library once and type every entry point.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  The CALM-ViT path has no non-HIP fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.calm_abi_version() != 1:
+        raise RuntimeError("libcalmvit_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = "invalid argument/unsupported shape" if rc < 0 else "hipError_t"
+        raise RuntimeError(f"{what} failed: code {rc} ({kind})")

@@ -1,0 +1,206 @@
+"""Tensor-level front of the C-ABI: turns torch tensors into raw device pointers and enqueues the
+HIP kernels of libcalmvit_hip.so on torch's current HIP stream.  PyTorch is only the allocator
+and stream provider here.
+
+`get_backend()` returns the one product backend (HipBackend) and raises if the library cannot be
+loaded; HipBackend rejects non-CUDA tensors.  `use_backend()` exists so that tests/ can check the
+host-side autograd plumbing against a torch emulation of the C-ABI kept under tests/ — nothing
+in the package ever installs another backend.
+"""
+import contextlib
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_GELU_BWD, ACT_NONE  # noqa: F401  (re-exported)
+
+SN_EPS = 1e-12
+
+
+def _ptr(t, allow_none=False):
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError("required tensor is None")
+    if not t.is_cuda:
+        raise RuntimeError("CALM-ViT ops run only on the MI355X HIP path: got a CPU tensor "
+                           "(there is no CPU fallback; move the model and inputs to 'cuda')")
+    if t.dtype != torch.float32:
+        raise TypeError(f"fp32 tensor expected, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class SnPlan:
+    """Device-resident plan for the batched spectral-norm power iteration."""
+
+    def __init__(self, info, blob_dev, scratch, key):
+        self.info = info
+        self.blob_dev = blob_dev
+        self.scratch = scratch
+        self.key = key
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    # ---- GEMM -------------------------------------------------------------------------
+    def gemm(self, A, B, Cout, M, N, K, a, b, c, batch=(1, 1), alpha=1.0, inv_scale=None, bias=None,
+             col_scale=None, residual=None, r=(0, 0, 0), C_pre=None, aux=None, act=ACT_NONE,
+             accumulate=False, reduce_batch=False, split_k=0):
+        g = _lib.GemmArgs()
+        g.A, g.B, g.C = _ptr(A), _ptr(B), _ptr(Cout)
+        g.M, g.N, g.K = M, N, K
+        g.batch0, g.batch1 = batch
+        g.a_rs, g.a_cs, g.a_b0, g.a_b1 = a
+        g.b_rs, g.b_cs, g.b_b0, g.b_b1 = b
+        g.c_rs, g.c_b0, g.c_b1 = c
+        g.alpha = alpha
+        g.inv_scale = _ptr(inv_scale, True)
+        g.bias = _ptr(bias, True)
+        g.col_scale = _ptr(col_scale, True)
+        g.residual = _ptr(residual, True)
+        g.r_rs, g.r_b0, g.r_b1 = r
+        g.C_pre = _ptr(C_pre, True)
+        g.aux = _ptr(aux, True)
+        g.act = act
+        g.accumulate = int(accumulate)
+        g.reduce_batch = int(reduce_batch)
+        g.split_k = split_k
+        g.dtype = _lib.F32
+        _lib.check(self.lib.calm_gemm(C.byref(g), _stream()), "calm_gemm")
+
+    # ---- LayerNorm --------------------------------------------------------------------
+    def layernorm_fwd(self, x, w, y, mean, rstd, rows, D, eps):
+        _lib.check(self.lib.calm_layernorm_fwd(_ptr(x), _ptr(w), _ptr(y), _ptr(mean), _ptr(rstd), rows, D, eps,
+                                               _stream()), "calm_layernorm_fwd")
+
+    def layernorm_bwd(self, dy, x, w, mean, rstd, dx, dw, rows, D):
+        _lib.check(self.lib.calm_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dx),
+                                               _ptr(dw), rows, D, _stream()), "calm_layernorm_bwd")
+
+    # ---- RoPE -------------------------------------------------------------------------
+    def rope_fwd(self, content, xr, inv_freq, table, out, B, S, H, dc, dr):
+        _lib.check(self.lib.calm_rope_fwd(_ptr(content, True), _ptr(xr), _ptr(inv_freq), _ptr(table), _ptr(out),
+                                          B, S, H, dc, dr, _stream()), "calm_rope_fwd")
+
+    def rope_bwd(self, d_out, xr, table, d_content, d_xr, d_inv_freq, B, S, H, dc, dr):
+        _lib.check(self.lib.calm_rope_bwd(_ptr(d_out), _ptr(xr), _ptr(table), _ptr(d_content, True), _ptr(d_xr),
+                                          _ptr(d_inv_freq), B, S, H, dc, dr, _stream()), "calm_rope_bwd")
+
+    # ---- softmax ----------------------------------------------------------------------
+    def softmax_fwd(self, x, rows, cols):
+        _lib.check(self.lib.calm_softmax_fwd(_ptr(x), rows, cols, _stream()), "calm_softmax_fwd")
+
+    def softmax_bwd(self, p, dp, rows, cols):
+        _lib.check(self.lib.calm_softmax_bwd(_ptr(p), _ptr(dp), rows, cols, _stream()), "calm_softmax_bwd")
+
+    def sum_heads(self, dl, dm, B, H, per_head):
+        _lib.check(self.lib.calm_sum_heads(_ptr(dl), _ptr(dm), B, H, per_head, _stream()), "calm_sum_heads")
+
+    # ---- latent -----------------------------------------------------------------------
+    def latent_fwd(self, mv, noise, z, std, kl_sum, rows, mvh):
+        _lib.check(self.lib.calm_latent_fwd(_ptr(mv), _ptr(noise, True), _ptr(z), _ptr(std), _ptr(kl_sum), rows,
+                                            mvh, _stream()), "calm_latent_fwd")
+
+    def latent_bwd(self, dz, d_kl_sum, mv, noise, std, dmv, rows, mvh):
+        _lib.check(self.lib.calm_latent_bwd(_ptr(dz, True), _ptr(d_kl_sum, True), _ptr(mv), _ptr(noise, True),
+                                            _ptr(std), _ptr(dmv), rows, mvh, _stream()), "calm_latent_bwd")
+
+    # ---- spectral norm ----------------------------------------------------------------
+    def sn_plan(self, layers):
+        """layers: list of (w2d, u, v, sigma) tensors.  Returns an SnPlan bound to their addresses."""
+        n = len(layers)
+        arr = (_lib.SnLayer * n)()
+        for i, (w, u, v, sg) in enumerate(layers):
+            rows = w.shape[0]
+            cols = w.numel() // rows
+            arr[i].w, arr[i].u, arr[i].v, arr[i].sigma = _ptr(w), _ptr(u), _ptr(v), _ptr(sg)
+            arr[i].rows, arr[i].cols = rows, cols
+        info = _lib.SnPlanInfo()
+        _lib.check(self.lib.calm_sn_plan(arr, n, None, C.byref(info)), "calm_sn_plan")
+        blob = np.zeros(info.blob_bytes, dtype=np.uint8)
+        _lib.check(self.lib.calm_sn_plan(arr, n, blob.ctypes.data, C.byref(info)), "calm_sn_plan")
+        dev = layers[0][0].device
+        blob_dev = torch.from_numpy(blob).to(dev)
+        scratch = torch.empty(int(info.scratch_floats), dtype=torch.float32, device=dev)
+        key = tuple(t.data_ptr() for layer in layers for t in layer)
+        return SnPlan(info, blob_dev, scratch, key)
+
+    def sn_power_iter(self, plan, training):
+        _lib.check(self.lib.calm_sn_power_iter(plan.blob_dev.data_ptr(), C.byref(plan.info), int(training), SN_EPS,
+                                               _ptr(plan.scratch), _stream()), "calm_sn_power_iter")
+
+    def sn_weight_bwd(self, G, w, u, v, sigma, ls, dW, d_ls, rows, cols):
+        scratch = torch.empty(rows + 2, dtype=torch.float32, device=G.device)
+        _lib.check(self.lib.calm_sn_weight_bwd(_ptr(G), _ptr(w), _ptr(u), _ptr(v), _ptr(sigma), _ptr(ls, True),
+                                               _ptr(dW), _ptr(d_ls, True), rows, cols, _ptr(scratch), _stream()),
+                   "calm_sn_weight_bwd")
+
+    # ---- tokenisation / conv ----------------------------------------------------------
+    def image_to_rows(self, img, rows, B, S):
+        _lib.check(self.lib.calm_image_to_rows(_ptr(img), _ptr(rows), B, S, _stream()), "calm_image_to_rows")
+
+    def rows_to_image(self, rows, img, B, S):
+        _lib.check(self.lib.calm_rows_to_image(_ptr(rows), _ptr(img), B, S, _stream()), "calm_rows_to_image")
+
+    def grid_transpose(self, x, out, B, S):
+        _lib.check(self.lib.calm_grid_transpose(_ptr(x), _ptr(out), B, S, _stream()), "calm_grid_transpose")
+
+    def dwconv_fwd(self, x, w, inv_scale, bias, y, y_pre, act, B, S, Cch):
+        _lib.check(self.lib.calm_dwconv3x3_fwd(_ptr(x), _ptr(w), _ptr(inv_scale, True), _ptr(bias, True), _ptr(y),
+                                               _ptr(y_pre, True), act, B, S, Cch, _stream()), "calm_dwconv3x3_fwd")
+
+    def dwconv_bwd(self, dz, x, w, inv_scale, dx, dw, db, B, S, Cch):
+        _lib.check(self.lib.calm_dwconv3x3_bwd(_ptr(dz), _ptr(x), _ptr(w), _ptr(inv_scale, True), _ptr(dx),
+                                               _ptr(dw), _ptr(db), B, S, Cch, _stream()), "calm_dwconv3x3_bwd")
+
+    # ---- helpers ----------------------------------------------------------------------
+    def add(self, a, b, out, n):
+        _lib.check(self.lib.calm_add(_ptr(a), _ptr(b), _ptr(out), n, _stream()), "calm_add")
+
+    def gelu_bwd(self, dy, z, dz, n):
+        _lib.check(self.lib.calm_gelu_bwd(_ptr(dy), _ptr(z), _ptr(dz), n, _stream()), "calm_gelu_bwd")
+
+    def colsum(self, x, out, rows, cols):
+        _lib.check(self.lib.calm_colsum(_ptr(x), _ptr(out), rows, cols, _stream()), "calm_colsum")
+
+    def row_scale(self, x, s, out, rows, cols):
+        _lib.check(self.lib.calm_row_scale(_ptr(x), _ptr(s), _ptr(out), rows, cols, _stream()), "calm_row_scale")
+
+    def mean_seq_fwd(self, x, y, B, S, D):
+        _lib.check(self.lib.calm_mean_seq_fwd(_ptr(x), _ptr(y), B, S, D, _stream()), "calm_mean_seq_fwd")
+
+    def mean_seq_bwd(self, dy, dx, B, S, D):
+        _lib.check(self.lib.calm_mean_seq_bwd(_ptr(dy), _ptr(dx), B, S, D, _stream()), "calm_mean_seq_bwd")
+
+
+_backend = None
+
+
+def get_backend():
+    """The product backend.  Raises RuntimeError when libcalmvit_hip.so is not built/loadable."""
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()
+    return _backend
+
+
+@contextlib.contextmanager
+def use_backend(b):
+    """TEST HOOK ONLY (tests/): run the host logic against another implementation of the C-ABI."""
+    global _backend
+    old = _backend
+    _backend = b
+    try:
+        yield b
+    finally:
+        _backend = old

@@ -1,0 +1,319 @@
+// calm_gemm: strided / batched / split-K fp32 GEMM with fused epilogue for gfx950.
+//
+// Tile 128x128x16 per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 v_mfma_f32_32x32x2_f32
+// accumulators).  Both operands are staged K-MAJOR in LDS ([k][row], row stride 132 floats): fragment
+// reads are then one conflict-free ds_read_b32 per MFMA operand for every source layout, and the
+// four source layouts (k- or row-contiguous A and B) only differ in the global->register->LDS
+// staging.  fp32 MFMA issues every 64 cycles per SIMD, so LDS/VALU work hides under it; the loop is
+// a register-prefetch double buffer (global loads of tile t+1 issued before the MFMAs of tile t).
+// Workgroup ids are remapped so that consecutive tiles (n fastest: they share an A panel) land on
+// the same XCD / L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132, NTHREADS = 256;
+
+struct GemmP {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    int batch1;
+    long a_rs, a_cs, a_b0, a_b1;
+    long b_rs, b_cs, b_b0, b_b1;
+    long c_rs, c_b0, c_b1;
+    float alpha;
+    const float* inv_scale; const float* bias; const float* col_scale;
+    const float* residual; long r_rs, r_b0, r_b1;
+    float* C_pre; const float* aux;
+    int act, accumulate;
+    int kpb;        // k-blocks per batch entry
+    int kb_total;   // k-blocks in the whole reduction space walked by grid.y
+    int kb_per_z;   // k-blocks per grid.y slice
+    int atomic;     // partial results combined with fp32 atomics (split-K / batch-reduce)
+    int tiles_m, tiles_n;
+};
+
+template <bool KC, int VEC>
+__device__ __forceinline__ void load_operand(const float* __restrict__ base, long rs, long cs, int row0,
+                                             int nrows, int k0, int K, float (&reg)[8]) {
+    const int tid = threadIdx.x;
+    if constexpr (VEC == 4) {
+        if constexpr (KC) {
+            const int k = k0 + 4 * (tid & 3);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = row0 + (tid >> 2) + 64 * i;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row < nrows && k < K) v = *reinterpret_cast<const f32x4*>(base + (long)row * rs + k);
+                reg[4 * i + 0] = v[0]; reg[4 * i + 1] = v[1]; reg[4 * i + 2] = v[2]; reg[4 * i + 3] = v[3];
+            }
+        } else {
+            const int row = row0 + 4 * (tid & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = k0 + (tid >> 5) + 8 * i;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (row < nrows && k < K) v = *reinterpret_cast<const f32x4*>(base + (long)k * cs + row);
+                reg[4 * i + 0] = v[0]; reg[4 * i + 1] = v[1]; reg[4 * i + 2] = v[2]; reg[4 * i + 3] = v[3];
+            }
+        }
+    } else {
+        if constexpr (KC) {
+            const int k = k0 + (tid & 15);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = row0 + (tid >> 4) + 16 * i;
+                reg[i] = (row < nrows && k < K) ? base[(long)row * rs + k] : 0.f;
+            }
+        } else {
+            const int row = row0 + (tid & 127);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int k = k0 + (tid >> 7) + 2 * i;
+                reg[i] = (row < nrows && k < K) ? base[(long)k * cs + row] : 0.f;
+            }
+        }
+    }
+}
+
+template <bool KC, int VEC>
+__device__ __forceinline__ void store_operand(float (*T)[LDT], const float (&reg)[8]) {
+    const int tid = threadIdx.x;
+    if constexpr (VEC == 4) {
+        if constexpr (KC) {
+            const int kq = 4 * (tid & 3);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = (tid >> 2) + 64 * i;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) T[kq + j][row] = reg[4 * i + j];
+            }
+        } else {
+            const int row = 4 * (tid & 31);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int k = (tid >> 5) + 8 * i;
+                f32x4 v = {reg[4 * i + 0], reg[4 * i + 1], reg[4 * i + 2], reg[4 * i + 3]};
+                *reinterpret_cast<f32x4*>(&T[k][row]) = v;
+            }
+        }
+    } else {
+        if constexpr (KC) {
+            const int k = tid & 15;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) T[k][(tid >> 4) + 16 * i] = reg[i];
+        } else {
+            const int row = tid & 127;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) T[(tid >> 7) + 2 * i][row] = reg[i];
+        }
+    }
+}
+
+template <bool AKC, bool BKC, int VEC>
+__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    // XCD-aware, bijective tile remap (blocks b and b+8 share an XCD).
+    const int tiles = p.tiles_m * p.tiles_n;
+    int lin = blockIdx.x;
+    if (tiles >= 8) {
+        const int q = tiles >> 3, rem = tiles & 7, x = lin & 7, idx = lin >> 3;
+        lin = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + idx;
+    }
+    const int tn = lin % p.tiles_n, tm = lin / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z = blockIdx.y;
+    const int kb_begin = z * p.kb_per_z;
+    const int kb_end = min(kb_begin + p.kb_per_z, p.kb_total);
+    if (kb_begin >= kb_end && p.atomic) return;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float ra[8], rb[8];
+
+    auto fetch = [&](int kb) {
+        const int b = kb / p.kpb;
+        const int k0 = (kb - b * p.kpb) * BK;
+        const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
+        load_operand<AKC, VEC>(p.A + b0 * p.a_b0 + b1 * p.a_b1, p.a_rs, p.a_cs, m0, p.M, k0, p.K, ra);
+        load_operand<BKC, VEC>(p.B + b0 * p.b_b0 + b1 * p.b_b1, p.b_rs, p.b_cs, n0, p.N, k0, p.K, rb);
+    };
+
+    int buf = 0;
+    if (kb_begin < kb_end) {
+        fetch(kb_begin);
+        store_operand<AKC, VEC>(As[0], ra);
+        store_operand<BKC, VEC>(Bs[0], rb);
+    }
+    __syncthreads();
+
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+        const bool more = kb + 1 < kb_end;
+        if (more) fetch(kb + 1);
+#pragma unroll
+        for (int s = 0; s < BK / 2; ++s) {
+            const int kk = 2 * s + h;
+            const float a0 = As[buf][kk][wm * 64 + r];
+            const float a1 = As[buf][kk][wm * 64 + 32 + r];
+            const float b0 = Bs[buf][kk][wn * 64 + r];
+            const float b1 = Bs[buf][kk][wn * 64 + 32 + r];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            store_operand<AKC, VEC>(As[buf ^ 1], ra);
+            store_operand<BKC, VEC>(Bs[buf ^ 1], rb);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    // ---- epilogue ----
+    float scale = p.alpha;
+    if (p.inv_scale) scale = scale / p.inv_scale[0];
+    const int zc = p.atomic ? 0 : z;
+    const int cb0 = zc / p.batch1, cb1 = zc - cb0 * p.batch1;
+    const long coff = cb0 * p.c_b0 + cb1 * p.c_b1;
+    float* __restrict__ Cb = p.C + coff;
+    float* __restrict__ Pb = p.C_pre ? p.C_pre + coff : nullptr;
+    const float* __restrict__ Xb = p.aux ? p.aux + coff : nullptr;
+    const float* __restrict__ Rb = p.residual ? p.residual + cb0 * p.r_b0 + cb1 * p.r_b1 : nullptr;
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + 32 * j + r;
+            if (col >= p.N) continue;
+            const float bj = p.bias ? p.bias[col] : 0.f;
+            const float sj = p.col_scale ? p.col_scale[col] : 1.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                const long off = (long)row * p.c_rs + col;
+                float v = acc[i][j][e] * scale;
+                if (p.atomic) {
+                    atomicAdd(Cb + off, v);
+                    continue;
+                }
+                v += bj;
+                if (Pb) Pb[off] = v;
+                if (p.act == CALM_ACT_GELU) v = gelu_erf_f(v);
+                else if (p.act == CALM_ACT_GELU_BWD) v *= gelu_erf_grad_f(Xb[off]);
+                v *= sj;
+                if (Rb) v += Rb[(long)row * p.r_rs + col];
+                if (p.accumulate) v += Cb[off];
+                Cb[off] = v;
+            }
+        }
+    }
+}
+
+template <bool AKC, bool BKC, int VEC>
+int launch(const GemmP& p, dim3 grid, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, VEC>), grid, dim3(NTHREADS), 0, s, p);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+inline bool mult4(int64_t x) { return (x & 3) == 0; }
+
+}  // namespace
+
+extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
+    if (!a || !a->A || !a->B || !a->C) return CALM_E_INVAL;
+    if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch0 <= 0 || a->batch1 <= 0) return CALM_E_INVAL;
+    if (a->dtype != CALM_F32) return CALM_E_UNSUPP;
+    if (a->a_rs != 1 && a->a_cs != 1) return CALM_E_LAYOUT;
+    if (a->b_rs != 1 && a->b_cs != 1) return CALM_E_LAYOUT;
+    if (a->act == CALM_ACT_GELU_BWD && !a->aux) return CALM_E_INVAL;
+    if (a->act < 0 || a->act > CALM_ACT_GELU_BWD) return CALM_E_INVAL;
+    hipStream_t s = as_stream(stream);
+
+    GemmP p;
+    p.A = (const float*)a->A; p.B = (const float*)a->B; p.C = (float*)a->C;
+    p.M = a->M; p.N = a->N; p.K = a->K;
+    p.batch1 = a->batch1;
+    p.a_rs = a->a_rs; p.a_cs = a->a_cs; p.a_b0 = a->a_b0; p.a_b1 = a->a_b1;
+    p.b_rs = a->b_rs; p.b_cs = a->b_cs; p.b_b0 = a->b_b0; p.b_b1 = a->b_b1;
+    p.c_rs = a->c_rs; p.c_b0 = a->c_b0; p.c_b1 = a->c_b1;
+    p.alpha = a->alpha; p.inv_scale = a->inv_scale; p.bias = a->bias; p.col_scale = a->col_scale;
+    p.residual = (const float*)a->residual; p.r_rs = a->r_rs; p.r_b0 = a->r_b0; p.r_b1 = a->r_b1;
+    p.C_pre = (float*)a->C_pre; p.aux = (const float*)a->aux;
+    p.act = a->act; p.accumulate = a->accumulate;
+    p.tiles_m = (a->M + BM - 1) / BM;
+    p.tiles_n = (a->N + BN - 1) / BN;
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int batch = a->batch0 * a->batch1;
+    p.kpb = (a->K + BK - 1) / BK;
+
+    const bool trivial_epi = !a->bias && !a->col_scale && !a->residual && !a->C_pre && a->act == CALM_ACT_NONE;
+    int nsplit = 1;
+    p.atomic = 0;
+    if (a->reduce_batch) {
+        p.atomic = 1;
+        p.kb_total = batch * p.kpb;
+        nsplit = a->split_k > 1 ? a->split_k : (1024 + tiles - 1) / tiles;
+        const int max_split = (p.kb_total + 7) / 8;
+        if (nsplit > max_split) nsplit = max_split;
+        if (nsplit < 1) nsplit = 1;
+    } else if (a->split_k > 1 || (a->split_k == 0 && batch == 1 && trivial_epi && tiles < 256 && p.kpb >= 64)) {
+        if (batch != 1) return CALM_E_UNSUPP;
+        nsplit = a->split_k > 1 ? a->split_k : (768 + tiles - 1) / tiles;
+        const int max_split = (p.kpb + 15) / 16;
+        if (nsplit > max_split) nsplit = max_split;
+        if (nsplit < 1) nsplit = 1;
+        p.kb_total = p.kpb;
+        p.atomic = nsplit > 1;
+    } else {
+        p.kb_total = batch * p.kpb;
+    }
+    if (p.atomic) {
+        if (!trivial_epi) return CALM_E_UNSUPP;
+        p.kb_per_z = (p.kb_total + nsplit - 1) / nsplit;
+        if (!a->accumulate) {
+            hipError_t e;
+            if (a->c_rs == a->N) e = hipMemsetAsync(p.C, 0, sizeof(float) * (size_t)a->M * a->N, s);
+            else e = hipMemset2DAsync(p.C, sizeof(float) * a->c_rs, 0, sizeof(float) * a->N, a->M, s);
+            if (e != hipSuccess) return (int)e;
+        }
+    } else {
+        p.kb_per_z = p.kpb;   // grid.y == batch
+    }
+    const int gy = (p.kb_total + p.kb_per_z - 1) / p.kb_per_z;
+    if (gy > 65535) return CALM_E_UNSUPP;
+    dim3 grid(tiles, gy);
+
+    const bool akc = a->a_cs == 1;
+    const bool bkc = a->b_cs == 1;
+    bool vec = aligned16(a->A) && aligned16(a->B) && mult4(a->a_b0) && mult4(a->a_b1) && mult4(a->b_b0) &&
+               mult4(a->b_b1);
+    vec = vec && (akc ? (mult4(a->K) && mult4(a->a_rs)) : (mult4(a->M) && mult4(a->a_cs)));
+    vec = vec && (bkc ? (mult4(a->K) && mult4(a->b_rs)) : (mult4(a->N) && mult4(a->b_cs)));
+
+    if (vec) {
+        if (akc && bkc) return launch<true, true, 4>(p, grid, s);
+        if (akc && !bkc) return launch<true, false, 4>(p, grid, s);
+        if (!akc && bkc) return launch<false, true, 4>(p, grid, s);
+        return launch<false, false, 4>(p, grid, s);
+    }
+    if (akc && bkc) return launch<true, true, 1>(p, grid, s);
+    if (akc && !bkc) return launch<true, false, 1>(p, grid, s);
+    if (!akc && bkc) return launch<false, true, 1>(p, grid, s);
+    return launch<false, false, 1>(p, grid, s);
+}

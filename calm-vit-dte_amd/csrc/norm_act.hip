@@ -1,0 +1,497 @@
+// HBM-bound streaming kernels of the CALM-ViT path: LayerNorm, learned RoPE + head assembly,
+// row softmax, latent sampling/KL, and small helpers.  All are one-wave-per-row or grid-stride
+// kernels with coalesced (16-byte where alignment allows) accesses and wave shuffles for the
+// row reductions; cross-row reductions (dw, d_inv_freq, kl, bias grads) are summed per block
+// in registers/LDS first and leave the block as one atomic per output element.
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int MAX_BLOCKS = 2048;   // 256 CUs x 8 blocks
+
+inline int grid_for(int64_t work_items, int per_block) {
+    int64_t g = (work_items + per_block - 1) / per_block;
+    if (g > MAX_BLOCKS) g = MAX_BLOCKS;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ------------------------------------------------------------------ LayerNorm
+// one wave per row, rows grid-strided over waves
+__global__ __launch_bounds__(NT) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                    float* __restrict__ y, float* __restrict__ mean,
+                                                    float* __restrict__ rstd, long rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (NT / 64);
+    for (long row = wave; row < rows; row += nwaves) {
+        const float* xr = x + row * D;
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += xr[c];
+        const float mu = wave_sum(s) / D;
+        float q = 0.f;
+        for (int c = lane; c < D; c += 64) { const float d = xr[c] - mu; q += d * d; }
+        const float rs = rsqrtf(wave_sum(q) / D + eps);
+        float* yr = y + row * D;
+        for (int c = lane; c < D; c += 64) yr[c] = (xr[c] - mu) * rs * w[c];
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+constexpr int LN_MAXC = 32;   // columns per lane kept in registers for dw (D <= 2048)
+
+__global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                    const float* __restrict__ w, const float* __restrict__ mean,
+                                                    const float* __restrict__ rstd, float* __restrict__ dx,
+                                                    float* __restrict__ dw, long rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (NT / 64);
+    float dwacc[LN_MAXC];
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) dwacc[i] = 0.f;
+    for (long row = wave; row < rows; row += nwaves) {
+        const float* xr = x + row * D;
+        const float* gr = dy + row * D;
+        const float mu = mean[row], rs = rstd[row];
+        float c1 = 0.f, c2 = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float g = gr[c] * w[c];
+            const float xh = (xr[c] - mu) * rs;
+            c1 += g; c2 += g * xh;
+        }
+        c1 = wave_sum(c1) / D; c2 = wave_sum(c2) / D;
+        float* dr = dx + row * D;
+#pragma unroll
+        for (int i = 0; i < LN_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < D) {
+                const float xh = (xr[c] - mu) * rs;
+                const float gy = gr[c];
+                dr[c] = rs * (gy * w[c] - c1 - xh * c2);
+                dwacc[i] += gy * xh;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXC; ++i) {
+        const int c = lane + 64 * i;
+        if (c < D) atomicAdd(dw + c, dwacc[i]);
+    }
+}
+
+// ------------------------------------------------------------------ RoPE
+__global__ void rope_table_kernel(const float* __restrict__ inv_freq, float* __restrict__ table, int S, int half) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= S * half) return;
+    const int s = i / half, j = i - s * half;
+    const float ang = (float)s * inv_freq[j];
+    table[i] = cosf(ang);
+    table[S * half + i] = sinf(ang);
+}
+
+__global__ __launch_bounds__(NT) void rope_fwd_kernel(const float* __restrict__ content, const float* __restrict__ xr,
+                                                      const float* __restrict__ table, float* __restrict__ out,
+                                                      long nrows, int S, int H, int dc, int dr) {
+    const int half = dr >> 1;
+    const int wd = dc + half;                   // work items per (b,s,h) row
+    const long total = nrows * wd;
+    const float* cosT = table;
+    const float* sinT = table + (long)S * half;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long row = i / wd;
+        const int j = (int)(i - row * wd);
+        float* o = out + row * (dc + dr);
+        if (j < dc) {
+            o[j] = content[row * dc + j];
+        } else {
+            const int jj = j - dc;
+            const int s = (int)((row / H) % S);
+            const float c = cosT[s * half + jj], sn = sinT[s * half + jj];
+            const float x1 = xr[row * dr + jj], x2 = xr[row * dr + jj + half];
+            o[dc + jj] = x1 * c - x2 * sn;
+            o[dc + jj + half] = x2 * c + x1 * sn;
+        }
+    }
+}
+
+constexpr int ROPE_MAX_HALF = 256;
+
+__global__ __launch_bounds__(NT) void rope_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ xr,
+                                                      const float* __restrict__ table, float* __restrict__ d_content,
+                                                      float* __restrict__ d_xr, float* __restrict__ d_inv_freq,
+                                                      long nrows, int S, int H, int dc, int dr) {
+    __shared__ float facc[ROPE_MAX_HALF];
+    const int half = dr >> 1;
+    for (int j = threadIdx.x; j < half; j += NT) facc[j] = 0.f;
+    __syncthreads();
+    const int wd = dc + half;
+    const long total = nrows * wd;
+    const float* cosT = table;
+    const float* sinT = table + (long)S * half;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long row = i / wd;
+        const int j = (int)(i - row * wd);
+        const float* g = d_out + row * (dc + dr);
+        if (j < dc) {
+            d_content[row * dc + j] = g[j];
+        } else {
+            const int jj = j - dc;
+            const int s = (int)((row / H) % S);
+            const float c = cosT[s * half + jj], sn = sinT[s * half + jj];
+            const float g1 = g[dc + jj], g2 = g[dc + jj + half];
+            const float x1 = xr[row * dr + jj], x2 = xr[row * dr + jj + half];
+            d_xr[row * dr + jj] = g1 * c + g2 * sn;
+            d_xr[row * dr + jj + half] = g2 * c - g1 * sn;
+            // d/d(angle): y1 = x1 c - x2 s, y2 = x2 c + x1 s ; angle = s * inv_freq[jj]
+            const float dang = g1 * (-x1 * sn - x2 * c) + g2 * (-x2 * sn + x1 * c);
+            atomicAdd(&facc[jj], dang * (float)s);
+        }
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < half; j += NT) atomicAdd(d_inv_freq + j, facc[j]);
+}
+
+// ------------------------------------------------------------------ softmax (one wave per row)
+constexpr int SM_MAXC = 16;   // cols <= 1024
+
+__global__ __launch_bounds__(NT) void softmax_fwd_kernel(float* __restrict__ x, long rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (NT / 64);
+    for (long row = wave; row < rows; row += nwaves) {
+        float* xr = x + row * cols;
+        float v[SM_MAXC];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < SM_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < cols ? xr[c] : -INFINITY;
+            m = fmaxf(m, v[i]);
+        }
+        m = wave_max(m);
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < SM_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < cols ? expf(v[i] - m) : 0.f;
+            s += v[i];
+        }
+        const float inv = 1.0f / wave_sum(s);
+#pragma unroll
+        for (int i = 0; i < SM_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cols) xr[c] = v[i] * inv;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void softmax_bwd_kernel(const float* __restrict__ p, float* __restrict__ dp,
+                                                         long rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (NT / 64);
+    for (long row = wave; row < rows; row += nwaves) {
+        const float* pr = p + row * cols;
+        float* gr = dp + row * cols;
+        float pv[SM_MAXC], gv[SM_MAXC];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < SM_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            pv[i] = c < cols ? pr[c] : 0.f;
+            gv[i] = c < cols ? gr[c] : 0.f;
+            s += pv[i] * gv[i];
+        }
+        s = wave_sum(s);
+#pragma unroll
+        for (int i = 0; i < SM_MAXC; ++i) {
+            const int c = lane + 64 * i;
+            if (c < cols) gr[c] = pv[i] * (gv[i] - s);
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void sum_heads_kernel(const float* __restrict__ dl, float* __restrict__ dm,
+                                                       int B, int H, long per_head) {
+    const long total = (long)B * per_head;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long b = i / per_head, r = i - b * per_head;
+        const float* src = dl + b * H * per_head + r;
+        float s = 0.f;
+        for (int h = 0; h < H; ++h) s += src[h * per_head];
+        dm[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------ latent sampling + KL
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+__global__ __launch_bounds__(NT) void latent_fwd_kernel(const float* __restrict__ mv, const float* __restrict__ noise,
+                                                        float* __restrict__ z, float* __restrict__ std_out,
+                                                        float* __restrict__ kl_sum, long rows, int mvh) {
+    __shared__ float red[4];
+    const long total = rows * mvh;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long row = i / mvh;
+        const int c = (int)(i - row * mvh);
+        const float mean = mv[row * 2 * mvh + c];
+        const float raw = mv[row * 2 * mvh + mvh + c];
+        const float sd = softplus_f(raw) + 1e-6f;
+        z[i] = noise ? mean + noise[i] * sd : mean;
+        std_out[i] = sd;
+        acc += 1.0f + 2.0f * logf(sd) - mean * mean - sd * sd;
+    }
+    acc = block_sum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(kl_sum, acc);
+}
+
+__global__ __launch_bounds__(NT) void latent_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ d_kl_sum,
+                                                        const float* __restrict__ mv, const float* __restrict__ noise,
+                                                        const float* __restrict__ std_in, float* __restrict__ dmv,
+                                                        long rows, int mvh) {
+    const long total = rows * mvh;
+    const float dk = d_kl_sum ? d_kl_sum[0] : 0.f;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long row = i / mvh;
+        const int c = (int)(i - row * mvh);
+        const float mean = mv[row * 2 * mvh + c];
+        const float raw = mv[row * 2 * mvh + mvh + c];
+        const float sd = std_in[i];
+        const float g = dz ? dz[i] : 0.f;
+        const float dmean = g - 2.0f * dk * mean;
+        const float dstd = (noise ? g * noise[i] : 0.f) + dk * (2.0f / sd - 2.0f * sd);
+        const float sig = raw > 20.f ? 1.0f : 1.0f / (1.0f + expf(-raw));
+        dmv[row * 2 * mvh + c] = dmean;
+        dmv[row * 2 * mvh + mvh + c] = dstd * sig;
+    }
+}
+
+// ------------------------------------------------------------------ helpers
+__global__ __launch_bounds__(NT) void add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                 float* __restrict__ out, long n4, long n) {
+    const long stride = (long)gridDim.x * NT;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += stride) {
+        const f32x4 x = reinterpret_cast<const f32x4*>(a)[i];
+        const f32x4 y = reinterpret_cast<const f32x4*>(b)[i];
+        reinterpret_cast<f32x4*>(out)[i] = x + y;
+    }
+    for (long i = 4 * n4 + (long)blockIdx.x * NT + threadIdx.x; i < n; i += stride) out[i] = a[i] + b[i];
+}
+
+__global__ __launch_bounds__(NT) void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
+                                                      float* __restrict__ dz, long n) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT)
+        dz[i] = dy[i] * gelu_erf_grad_f(z[i]);
+}
+
+constexpr int COLSUM_MAXC = 4096;
+__global__ __launch_bounds__(NT) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows,
+                                                    int cols) {
+    __shared__ float acc[COLSUM_MAXC];
+    for (int c = threadIdx.x; c < cols; c += NT) acc[c] = 0.f;
+    __syncthreads();
+    if (cols >= NT) {
+        // thread owns columns tid, tid+256, ...; block owns a strided set of rows
+        for (int c = threadIdx.x; c < cols; c += NT) {
+            float s = 0.f;
+            for (long r = blockIdx.x; r < rows; r += gridDim.x) s += x[r * cols + c];
+            acc[c] = s;
+        }
+    } else {
+        const long total = rows * cols;
+        for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT)
+            atomicAdd(&acc[(int)(i % cols)], x[i]);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < cols; c += NT) atomicAdd(out + c, acc[c]);
+}
+
+__global__ __launch_bounds__(NT) void row_scale_kernel(const float* __restrict__ x, const float* __restrict__ s,
+                                                       float* __restrict__ out, int rows, int cols) {
+    const long total = (long)rows * cols;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT)
+        out[i] = x[i] * s[i / cols];
+}
+
+__global__ __launch_bounds__(NT) void mean_seq_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
+                                                          int S, int D) {
+    const long total = (long)B * D;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long b = i / D;
+        const int d = (int)(i - b * D);
+        const float* src = x + b * S * D + d;
+        float s = 0.f;
+        for (int t = 0; t < S; ++t) s += src[(long)t * D];
+        y[i] = s / S;
+    }
+}
+
+__global__ __launch_bounds__(NT) void mean_seq_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B,
+                                                          int S, int D) {
+    const long total = (long)B * S * D;
+    const float inv = 1.0f / S;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long b = i / ((long)S * D);
+        const int d = (int)(i % D);
+        dx[i] = dy[b * D + d] * inv;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int calm_layernorm_fwd(const float* x, const float* w, float* y, float* mean, float* rstd, int64_t rows, int32_t D,
+                       float eps, void* stream) {
+    if (!x || !w || !y || !mean || !rstd || rows <= 0 || D <= 0) return CALM_E_INVAL;
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for(rows, NT / 64)), dim3(NT), 0, as_stream(stream), x, w, y, mean,
+                       rstd, (long)rows, D, eps);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                       float* dx, float* dw, int64_t rows, int32_t D, void* stream) {
+    if (!dy || !x || !w || !mean || !rstd || !dx || !dw || rows <= 0 || D <= 0) return CALM_E_INVAL;
+    if (D > 64 * LN_MAXC) return CALM_E_UNSUPP;
+    int g = grid_for(rows, NT / 64);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(g), dim3(NT), 0, as_stream(stream), dy, x, w, mean, rstd, dx, dw,
+                       (long)rows, D);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_rope_fwd(const float* content, const float* xr, const float* inv_freq, float* table, float* out, int32_t B,
+                  int32_t S, int32_t H, int32_t dc, int32_t dr, void* stream) {
+    if (!xr || !inv_freq || !table || !out || B <= 0 || S <= 0 || H <= 0 || dc < 0 || dr <= 0 || (dr & 1))
+        return CALM_E_INVAL;
+    if (dc > 0 && !content) return CALM_E_INVAL;
+    const int half = dr / 2;
+    hipLaunchKernelGGL(rope_table_kernel, dim3((S * half + 255) / 256), dim3(256), 0, as_stream(stream), inv_freq,
+                       table, S, half);
+    CALM_LAUNCH_CHECK();
+    const long nrows = (long)B * S * H;
+    hipLaunchKernelGGL(rope_fwd_kernel, dim3(grid_for(nrows * (dc + half), NT)), dim3(NT), 0, as_stream(stream),
+                       content, xr, table, out, nrows, S, H, dc, dr);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_rope_bwd(const float* d_out, const float* xr, const float* table, float* d_content, float* d_xr,
+                  float* d_inv_freq, int32_t B, int32_t S, int32_t H, int32_t dc, int32_t dr, void* stream) {
+    if (!d_out || !xr || !table || !d_xr || !d_inv_freq || B <= 0 || S <= 0 || H <= 0 || dc < 0 || dr <= 0 ||
+        (dr & 1))
+        return CALM_E_INVAL;
+    if (dc > 0 && !d_content) return CALM_E_INVAL;
+    if (dr / 2 > ROPE_MAX_HALF) return CALM_E_UNSUPP;
+    const long nrows = (long)B * S * H;
+    int g = grid_for(nrows * (dc + dr / 2), NT);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(rope_bwd_kernel, dim3(g), dim3(NT), 0, as_stream(stream), d_out, xr, table, d_content, d_xr,
+                       d_inv_freq, nrows, S, H, dc, dr);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_softmax_fwd(float* x, int64_t rows, int32_t cols, void* stream) {
+    if (!x || rows <= 0 || cols <= 0) return CALM_E_INVAL;
+    if (cols > 64 * SM_MAXC) return CALM_E_UNSUPP;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3(grid_for(rows, NT / 64)), dim3(NT), 0, as_stream(stream), x,
+                       (long)rows, cols);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_softmax_bwd(const float* p, float* dp, int64_t rows, int32_t cols, void* stream) {
+    if (!p || !dp || rows <= 0 || cols <= 0) return CALM_E_INVAL;
+    if (cols > 64 * SM_MAXC) return CALM_E_UNSUPP;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3(grid_for(rows, NT / 64)), dim3(NT), 0, as_stream(stream), p, dp,
+                       (long)rows, cols);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_sum_heads(const float* dl, float* dm, int32_t B, int32_t H, int64_t per_head, void* stream) {
+    if (!dl || !dm || B <= 0 || H <= 0 || per_head <= 0) return CALM_E_INVAL;
+    hipLaunchKernelGGL(sum_heads_kernel, dim3(grid_for((int64_t)B * per_head, NT)), dim3(NT), 0, as_stream(stream),
+                       dl, dm, B, H, (long)per_head);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_latent_fwd(const float* mv, const float* noise, float* z, float* std_out, float* kl_sum, int64_t rows,
+                    int32_t mvh, void* stream) {
+    if (!mv || !z || !std_out || !kl_sum || rows <= 0 || mvh <= 0) return CALM_E_INVAL;
+    int g = grid_for(rows * mvh, NT);
+    if (g > 512) g = 512;
+    hipLaunchKernelGGL(latent_fwd_kernel, dim3(g), dim3(NT), 0, as_stream(stream), mv, noise, z, std_out, kl_sum,
+                       (long)rows, mvh);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_latent_bwd(const float* dz, const float* d_kl_sum, const float* mv, const float* noise, const float* std_in,
+                    float* dmv, int64_t rows, int32_t mvh, void* stream) {
+    if (!mv || !std_in || !dmv || rows <= 0 || mvh <= 0) return CALM_E_INVAL;
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(grid_for(rows * mvh, NT)), dim3(NT), 0, as_stream(stream), dz,
+                       d_kl_sum, mv, noise, std_in, dmv, (long)rows, mvh);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_add(const float* a, const float* b, float* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n <= 0) return CALM_E_INVAL;
+    const bool vec = aligned16(a) && aligned16(b) && aligned16(out);
+    const long n4 = vec ? n / 4 : 0;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(vec ? n4 + 1 : n, NT)), dim3(NT), 0, as_stream(stream), a, b, out,
+                       n4, (long)n);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_gelu_bwd(const float* dy, const float* z, float* dz, int64_t n, void* stream) {
+    if (!dy || !z || !dz || n <= 0) return CALM_E_INVAL;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n, NT)), dim3(NT), 0, as_stream(stream), dy, z, dz, (long)n);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* stream) {
+    if (!x || !out || rows <= 0 || cols <= 0) return CALM_E_INVAL;
+    if (cols > COLSUM_MAXC) return CALM_E_UNSUPP;
+    int g = cols >= NT ? (int)(rows < 512 ? rows : 512) : grid_for(rows * cols, NT * 8);
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(colsum_kernel, dim3(g), dim3(NT), 0, as_stream(stream), x, out, (long)rows, cols);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_row_scale(const float* x, const float* s, float* out, int32_t rows, int32_t cols, void* stream) {
+    if (!x || !s || !out || rows <= 0 || cols <= 0) return CALM_E_INVAL;
+    hipLaunchKernelGGL(row_scale_kernel, dim3(grid_for((int64_t)rows * cols, NT)), dim3(NT), 0, as_stream(stream), x,
+                       s, out, rows, cols);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_mean_seq_fwd(const float* x, float* y, int32_t B, int32_t S, int32_t D, void* stream) {
+    if (!x || !y || B <= 0 || S <= 0 || D <= 0) return CALM_E_INVAL;
+    hipLaunchKernelGGL(mean_seq_fwd_kernel, dim3(grid_for((int64_t)B * D, NT)), dim3(NT), 0, as_stream(stream), x, y,
+                       B, S, D);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_mean_seq_bwd(const float* dy, float* dx, int32_t B, int32_t S, int32_t D, void* stream) {
+    if (!dy || !dx || B <= 0 || S <= 0 || D <= 0) return CALM_E_INVAL;
+    hipLaunchKernelGGL(mean_seq_bwd_kernel, dim3(grid_for((int64_t)B * S * D, NT)), dim3(NT), 0, as_stream(stream),
+                       dy, dx, B, S, D);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,205 @@
+// Spectral norm for every wrapped Linear/Conv of the model in three launches (the reference runs
+// ~3 ATen calls per layer per forward: 882 mv + 883 div).
+//
+// Plan blob (built on the host by calm_sn_plan, copied to device memory by the caller):
+//   [SnLayerDev x n_layers][SnWork x n_work]
+// Work item = (layer, row chunk).  Phases (training):
+//   A: t[c]  += sum_{r in chunk} W[r,c] u[r]                (atomics into scratch; W^T u)
+//   B: v      = t / max(|t|, eps);  s[r] = W[r,:] . v       (every block renormalises t itself)
+//   C: u      = s / max(|s|, eps);  sigma = u . s           (one block per layer)
+// eval: phase B uses the stored v, phase C the stored u (sigma = u . W v, no update).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int ROWS_PER_WORK = 64;
+
+struct SnLayerDev {
+    const float* w; float* u; float* v; float* sigma;
+    int rows, cols;
+    long t_off, s_off;     // offsets into scratch (floats)
+};
+struct SnWork { int layer, row0, nrows, first; };
+
+__global__ __launch_bounds__(NT) void sn_phase_a(const SnLayerDev* __restrict__ layers, const SnWork* __restrict__ work,
+                                                 float* __restrict__ scratch) {
+    const SnWork wk = work[blockIdx.x];
+    const SnLayerDev L = layers[wk.layer];
+    float* t = scratch + L.t_off;
+    for (int c = threadIdx.x; c < L.cols; c += NT) {
+        float s = 0.f;
+        for (int r = wk.row0; r < wk.row0 + wk.nrows; ++r) s += L.w[(long)r * L.cols + c] * L.u[r];
+        atomicAdd(t + c, s);
+    }
+}
+
+__global__ __launch_bounds__(NT) void sn_phase_b(const SnLayerDev* __restrict__ layers, const SnWork* __restrict__ work,
+                                                 float* __restrict__ scratch, int training, float eps) {
+    __shared__ float red[4];
+    const SnWork wk = work[blockIdx.x];
+    const SnLayerDev L = layers[wk.layer];
+    const float* vin = training ? scratch + L.t_off : L.v;
+    float inv = 1.0f;
+    if (training) {
+        float q = 0.f;
+        for (int c = threadIdx.x; c < L.cols; c += NT) q += vin[c] * vin[c];
+        q = block_sum_256(q, red);
+        inv = 1.0f / fmaxf(sqrtf(q), eps);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* s = scratch + L.s_off;
+    for (int r = wk.row0 + wave; r < wk.row0 + wk.nrows; r += NT / 64) {
+        const float* wr = L.w + (long)r * L.cols;
+        float acc = 0.f;
+        for (int c = lane; c < L.cols; c += 64) acc += wr[c] * (vin[c] * inv);
+        acc = wave_sum(acc);
+        if (lane == 0) s[r] = acc;
+    }
+    if (training && wk.first) {
+        // safe: no block reads L.v in this launch when training (they all read t)
+        for (int c = threadIdx.x; c < L.cols; c += NT) L.v[c] = vin[c] * inv;
+    }
+}
+
+__global__ __launch_bounds__(NT) void sn_phase_c(const SnLayerDev* __restrict__ layers, const float* __restrict__ scratch,
+                                                 int training, float eps) {
+    __shared__ float red[4];
+    const SnLayerDev L = layers[blockIdx.x];
+    const float* s = scratch + L.s_off;
+    if (training) {
+        float q = 0.f;
+        for (int r = threadIdx.x; r < L.rows; r += NT) q += s[r] * s[r];
+        q = block_sum_256(q, red);
+        const float inv = 1.0f / fmaxf(sqrtf(q), eps);
+        float d = 0.f;
+        for (int r = threadIdx.x; r < L.rows; r += NT) {
+            const float un = s[r] * inv;
+            L.u[r] = un;
+            d += un * s[r];
+        }
+        d = block_sum_256(d, red);
+        if (threadIdx.x == 0) L.sigma[0] = d;
+    } else {
+        float d = 0.f;
+        for (int r = threadIdx.x; r < L.rows; r += NT) d += L.u[r] * s[r];
+        d = block_sum_256(d, red);
+        if (threadIdx.x == 0) L.sigma[0] = d;
+    }
+}
+
+// ---- weight gradient through W_orig / sigma ------------------------------------------------
+// pass 1: rowdot[r] = sum_k G[r,k] W[r,k] / sigma   (one wave per row)
+__global__ __launch_bounds__(NT) void sn_bwd_rowdot(const float* __restrict__ G, const float* __restrict__ w,
+                                                    const float* __restrict__ sigma, float* __restrict__ rowdot,
+                                                    int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int wave = blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (NT / 64);
+    const float inv = 1.0f / sigma[0];
+    for (int r = wave; r < rows; r += nwaves) {
+        float acc = 0.f;
+        for (int c = lane; c < cols; c += 64) acc += G[(long)r * cols + c] * w[(long)r * cols + c];
+        acc = wave_sum(acc);
+        if (lane == 0) rowdot[r] = acc * inv;
+    }
+}
+
+// pass 2: dW[r,k] = (ls[r] G[r,k] - dot * u[r] v[k]) / sigma,  dot = sum_r ls[r] rowdot[r]
+__global__ __launch_bounds__(NT) void sn_bwd_apply(const float* __restrict__ G, const float* __restrict__ u,
+                                                   const float* __restrict__ v, const float* __restrict__ sigma,
+                                                   const float* __restrict__ ls, const float* __restrict__ rowdot,
+                                                   float* __restrict__ dw, float* __restrict__ d_ls, int rows, int cols) {
+    __shared__ float red[4];
+    float d = 0.f;
+    for (int r = threadIdx.x; r < rows; r += NT) d += (ls ? ls[r] : 1.0f) * rowdot[r];
+    const float dot = block_sum_256(d, red);
+    const float inv = 1.0f / sigma[0];
+    const long total = (long)rows * cols;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const int r = (int)(i / cols);
+        const int c = (int)(i - (long)r * cols);
+        dw[i] = ((ls ? ls[r] : 1.0f) * G[i] - dot * u[r] * v[c]) * inv;
+    }
+    if (d_ls && blockIdx.x == 0)
+        for (int r = threadIdx.x; r < rows; r += NT) d_ls[r] = rowdot[r];
+}
+
+}  // namespace
+
+extern "C" {
+
+int calm_sn_plan(const calm_sn_layer* layers, int32_t n, void* blob_host, calm_sn_plan_info* info) {
+    if (!layers || n <= 0 || !info) return CALM_E_INVAL;
+    int n_work = 0;
+    long scratch = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!layers[i].w || !layers[i].u || !layers[i].v || !layers[i].sigma || layers[i].rows <= 0 ||
+            layers[i].cols <= 0)
+            return CALM_E_INVAL;
+        n_work += (layers[i].rows + ROWS_PER_WORK - 1) / ROWS_PER_WORK;
+        scratch += layers[i].rows + layers[i].cols;
+    }
+    info->n_layers = n;
+    info->n_work = n_work;
+    info->scratch_floats = scratch;
+    info->blob_bytes = (int64_t)sizeof(SnLayerDev) * n + (int64_t)sizeof(SnWork) * n_work;
+    if (!blob_host) return 0;
+    SnLayerDev* L = reinterpret_cast<SnLayerDev*>(blob_host);
+    SnWork* W = reinterpret_cast<SnWork*>(L + n);
+    long off = 0;
+    int wi = 0;
+    for (int i = 0; i < n; ++i) {
+        L[i].w = layers[i].w; L[i].u = layers[i].u; L[i].v = layers[i].v; L[i].sigma = layers[i].sigma;
+        L[i].rows = layers[i].rows; L[i].cols = layers[i].cols;
+        L[i].t_off = off; off += layers[i].cols;
+        L[i].s_off = off; off += layers[i].rows;
+        for (int r0 = 0; r0 < layers[i].rows; r0 += ROWS_PER_WORK) {
+            W[wi].layer = i; W[wi].row0 = r0;
+            W[wi].nrows = layers[i].rows - r0 < ROWS_PER_WORK ? layers[i].rows - r0 : ROWS_PER_WORK;
+            W[wi].first = r0 == 0;
+            ++wi;
+        }
+    }
+    return 0;
+}
+
+int calm_sn_power_iter(const void* plan_dev, const calm_sn_plan_info* info, int32_t training, float eps,
+                       float* scratch, void* stream) {
+    if (!plan_dev || !info || !scratch || info->n_layers <= 0 || info->n_work <= 0) return CALM_E_INVAL;
+    hipStream_t s = as_stream(stream);
+    const SnLayerDev* L = reinterpret_cast<const SnLayerDev*>(plan_dev);
+    const SnWork* W = reinterpret_cast<const SnWork*>(L + info->n_layers);
+    if (training) {
+        hipError_t e = hipMemsetAsync(scratch, 0, sizeof(float) * (size_t)info->scratch_floats, s);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(sn_phase_a, dim3(info->n_work), dim3(NT), 0, s, L, W, scratch);
+        CALM_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(sn_phase_b, dim3(info->n_work), dim3(NT), 0, s, L, W, scratch, training, eps);
+    CALM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(sn_phase_c, dim3(info->n_layers), dim3(NT), 0, s, L, (const float*)scratch, training, eps);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_sn_weight_bwd(const float* G, const float* w_orig, const float* u, const float* v, const float* sigma,
+                       const float* ls, float* d_w_orig, float* d_ls, int32_t rows, int32_t cols, float* scratch,
+                       void* stream) {
+    if (!G || !w_orig || !u || !v || !sigma || !d_w_orig || !scratch || rows <= 0 || cols <= 0) return CALM_E_INVAL;
+    hipStream_t s = as_stream(stream);
+    int g1 = (rows + 3) / 4;
+    if (g1 > 1024) g1 = 1024;
+    hipLaunchKernelGGL(sn_bwd_rowdot, dim3(g1), dim3(NT), 0, s, G, w_orig, sigma, scratch, rows, cols);
+    CALM_LAUNCH_CHECK();
+    long total = (long)rows * cols;
+    int g2 = (int)((total + NT * 4 - 1) / (NT * 4));
+    if (g2 > 1024) g2 = 1024;
+    if (g2 < 1) g2 = 1;
+    hipLaunchKernelGGL(sn_bwd_apply, dim3(g2), dim3(NT), 0, s, G, u, v, sigma, ls, (const float*)scratch, d_w_orig,
+                       d_ls, rows, cols);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // extern "C"

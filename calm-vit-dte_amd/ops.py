@@ -1,0 +1,569 @@
+"""Autograd operators of the CALM-ViT path.  Every forward/backward is an explicit sequence of
+C-ABI kernel launches (backend.py -> libcalmvit_hip.so); torch only allocates the tensors and
+threads the autograd graph.  File:line citations are into /root/reference/CALM-ViT/.
+
+Layout conventions: activations are contiguous fp32; token tensors are [B,S,D]; per-head tensors
+stay in the [B,S,H*hd] layout of the projection output (heads are addressed through GEMM strides,
+never materialised by a transpose).
+"""
+import math
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from .backend import ACT_GELU, ACT_GELU_BWD, ACT_NONE, get_backend
+
+_noise_override = None
+
+
+def set_noise_override(fn):
+    """Tests inject the latent noise (`fn(like) -> tensor`); None restores torch.randn_like."""
+    global _noise_override
+    _noise_override = fn
+
+
+def draw_noise(like):
+    return _noise_override(like) if _noise_override is not None else torch.randn_like(like)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------
+# GEMM patterns (x2: [M,K], w: [N,K], dy2: [M,N]; all row-major contiguous)
+# ---------------------------------------------------------------------------------------
+def _lin_fwd(be, x2, w, sigma, out, bias=None, act=ACT_NONE, col_scale=None, residual=None, pre=None):
+    M, K = x2.shape
+    N = w.shape[0]
+    be.gemm(x2, w, out, M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), inv_scale=sigma, bias=bias, act=act,
+            col_scale=col_scale, residual=residual, r=(N, 0, 0), C_pre=pre)
+
+
+def _lin_dgrad(be, dy2, w, sigma, dx, act=ACT_NONE, aux=None, residual=None, accumulate=False):
+    M, N = dy2.shape
+    K = w.shape[1]
+    be.gemm(dy2, w, dx, M, K, N, (N, 1, 0, 0), (1, K, 0, 0), (K, 0, 0), inv_scale=sigma, act=act, aux=aux,
+            residual=residual, r=(K, 0, 0), accumulate=accumulate)
+
+
+def _lin_wgrad(be, dy2, x2, G):
+    M, N = dy2.shape
+    K = x2.shape[1]
+    be.gemm(dy2, x2, G, N, K, M, (1, N, 0, 0), (1, K, 0, 0), (K, 0, 0))
+
+
+def _sn_wbwd(be, G, w, u, v, sigma, ls=None):
+    """G (grad wrt the effective weight, before LayerScale) -> (dW_orig, d_ls)."""
+    rows = w.shape[0]
+    cols = w.numel() // rows
+    dW = torch.empty_like(w)
+    d_ls = torch.empty_like(ls) if ls is not None else None
+    be.sn_weight_bwd(G, w, u, v, sigma, ls, dW, d_ls, rows, cols)
+    return dW, d_ls
+
+
+def _colsum(be, x2):
+    out = torch.zeros(x2.shape[1], dtype=x2.dtype, device=x2.device)
+    be.colsum(x2, out, x2.shape[0], x2.shape[1])
+    return out
+
+
+# ---------------------------------------------------------------------------------------
+class LayerNormFn(Function):
+    """LayerNorm(D, eps=1e-6, bias=False) (Vi_Tools:131-132,197,494)."""
+
+    @staticmethod
+    def forward(ctx, x, w, eps):
+        be = get_backend()
+        x = _c(x)
+        D = x.shape[-1]
+        rows = x.numel() // D
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=x.dtype, device=x.device)
+        rstd = torch.empty_like(mean)
+        be.layernorm_fwd(x, w, y, mean, rstd, rows, D, eps)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        be = get_backend()
+        x, w, mean, rstd = ctx.saved_tensors
+        dy = _c(dy)
+        D = x.shape[-1]
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        be.layernorm_bwd(dy, x, w, mean, rstd, dx, dw, x.numel() // D, D)
+        return dx, dw, None
+
+
+class SNLinearFn(Function):
+    """y = act(x W_orig^T / sigma + bias) * ls + residual — a spectral-normed nn.Linear with the
+    epilogues the block applies right after it (Vi_Tools:265-267, 276-277, 230-231, 300, 308)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, ls, residual, u, v, sigma, act):
+        be = get_backend()
+        x = _c(x)
+        K = x.shape[-1]
+        N = w.shape[0]
+        x2 = x.reshape(-1, K)
+        out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        pre = torch.empty_like(out) if act == ACT_GELU else None
+        res2 = _c(residual).reshape(-1, N) if residual is not None else None
+        _lin_fwd(be, x2, w, sigma, out.view(-1, N), bias=bias, act=act, col_scale=ls, residual=res2,
+                 pre=pre.view(-1, N) if pre is not None else None)
+        ctx.act = act
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x2, w, ls, u, v, sigma, pre)
+        ctx.xshape = x.shape
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        be = get_backend()
+        x2, w, ls, u, v, sigma, pre = ctx.saved_tensors
+        N, K = w.shape
+        dy2 = _c(dy).reshape(-1, N)
+        if ctx.act == ACT_GELU:
+            dz = torch.empty_like(dy2)
+            be.gelu_bwd(dy2, pre.view(-1, N), dz, dy2.numel())
+        else:
+            dz = dy2
+        G = torch.empty_like(w)
+        _lin_wgrad(be, dz, x2, G)
+        dW, d_ls = _sn_wbwd(be, G, w, u, v, sigma, ls)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2)
+            if ls is not None:
+                wl = torch.empty_like(w)
+                be.row_scale(w, ls, wl, N, K)
+            else:
+                wl = w
+            _lin_dgrad(be, dz, wl, sigma, dx)
+            dx = dx.view(ctx.xshape)
+        db = _colsum(be, dz) if ctx.has_bias else None
+        dres = dy if ctx.has_res else None
+        return dx, dW, db, d_ls, dres, None, None, None, None
+
+
+class MlpFn(Function):
+    """out = (gelu(x W1^T/s1 + b1) W2^T/s2 + b2) * ls + residual  (Vi_Tools:199-205,310-315 block MLP;
+    CALM_ViT_V2.py:49-53,76 cls head).  The GELU backward is fused into the dgrad GEMM epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, ls, residual, u1, v1, s1, u2, v2, s2):
+        be = get_backend()
+        x = _c(x)
+        K = x.shape[-1]
+        Hd = w1.shape[0]
+        N = w2.shape[0]
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        hp = torch.empty(M, Hd, dtype=x.dtype, device=x.device)
+        hg = torch.empty_like(hp)
+        _lin_fwd(be, x2, w1, s1, hg, bias=b1, act=ACT_GELU, pre=hp)
+        out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        res2 = _c(residual).reshape(-1, N) if residual is not None else None
+        _lin_fwd(be, hg, w2, s2, out.view(-1, N), bias=b2, col_scale=ls, residual=res2)
+        ctx.has_b1, ctx.has_b2, ctx.has_res = b1 is not None, b2 is not None, residual is not None
+        ctx.xshape = x.shape
+        ctx.save_for_backward(x2, hp, hg, w1, w2, ls, u1, v1, s1, u2, v2, s2)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        be = get_backend()
+        x2, hp, hg, w1, w2, ls, u1, v1, s1, u2, v2, s2 = ctx.saved_tensors
+        N, Hd = w2.shape
+        K = w1.shape[1]
+        do2 = _c(dout).reshape(-1, N)
+        G2 = torch.empty_like(w2)
+        _lin_wgrad(be, do2, hg, G2)
+        dW2, d_ls = _sn_wbwd(be, G2, w2, u2, v2, s2, ls)
+        db2 = _colsum(be, do2) if ctx.has_b2 else None
+        if ls is not None:
+            w2l = torch.empty_like(w2)
+            be.row_scale(w2, ls, w2l, N, Hd)
+        else:
+            w2l = w2
+        dhp = torch.empty_like(hp)
+        _lin_dgrad(be, do2, w2l, s2, dhp, act=ACT_GELU_BWD, aux=hp)
+        G1 = torch.empty_like(w1)
+        _lin_wgrad(be, dhp, x2, G1)
+        dW1, _ = _sn_wbwd(be, G1, w1, u1, v1, s1)
+        db1 = _colsum(be, dhp) if ctx.has_b1 else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2)
+            _lin_dgrad(be, dhp, w1, s1, dx)
+            dx = dx.view(ctx.xshape)
+        dres = dout if ctx.has_res else None
+        return dx, dW1, db1, dW2, db2, d_ls, dres, None, None, None, None, None, None
+
+
+class SeqLinearFn(Function):
+    """Y[b] = W X[b] / sigma along the sequence axis — the reference's permute->Linear->permute
+    (Vi_Tools:224-229,250-264,304-306) as a batched GEMM with a transposed operand (no copies)."""
+
+    @staticmethod
+    def forward(ctx, x, w, u, v, sigma):
+        be = get_backend()
+        x = _c(x)
+        B, S, D = x.shape
+        S2 = w.shape[0]
+        out = torch.empty(B, S2, D, dtype=x.dtype, device=x.device)
+        be.gemm(w, x, out, S2, D, S, (S, 1, 0, 0), (1, D, S * D, 0), (D, S2 * D, 0), batch=(B, 1), inv_scale=sigma)
+        ctx.save_for_backward(x, w, u, v, sigma)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        be = get_backend()
+        x, w, u, v, sigma = ctx.saved_tensors
+        B, S, D = x.shape
+        S2 = w.shape[0]
+        dy = _c(dy)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            # dX[b] = W^T dY[b] / sigma : A(m=s,k=s2) = W[s2,s]
+            be.gemm(w, dy, dx, S, D, S2, (1, S, 0, 0), (1, D, S2 * D, 0), (D, S * D, 0), batch=(B, 1),
+                    inv_scale=sigma)
+        # G[s2,s] = sum_b sum_d dY[b,s2,d] X[b,s,d]
+        G = torch.empty_like(w)
+        be.gemm(dy, x, G, S2, S, D, (D, 1, S2 * D, 0), (D, 1, S * D, 0), (S, 0, 0), batch=(B, 1), reduce_batch=True)
+        dW, _ = _sn_wbwd(be, G, w, u, v, sigma)
+        return dx, dW, None, None, None
+
+
+class RopeFn(Function):
+    """out[...,h,:dc] = content, out[...,h,dc:] = rope(xr) with learned inv_freq (Vi_Tools:80-95,275-285)."""
+
+    @staticmethod
+    def forward(ctx, content, xr, inv_freq, H):
+        be = get_backend()
+        xr = _c(xr)
+        B, S, W = xr.shape
+        dr = W // H
+        dc = 0
+        if content is not None:
+            content = _c(content)
+            dc = content.shape[-1] // H
+        table = torch.empty(2 * S * (dr // 2), dtype=xr.dtype, device=xr.device)
+        out = torch.empty(B, S, H * (dc + dr), dtype=xr.dtype, device=xr.device)
+        be.rope_fwd(content, xr, inv_freq, table, out, B, S, H, dc, dr)
+        ctx.dims = (B, S, H, dc, dr)
+        ctx.save_for_backward(xr, table)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        be = get_backend()
+        xr, table = ctx.saved_tensors
+        B, S, H, dc, dr = ctx.dims
+        dout = _c(dout)
+        d_xr = torch.empty_like(xr)
+        d_content = torch.empty(B, S, H * dc, dtype=xr.dtype, device=xr.device) if dc > 0 else None
+        d_if = torch.zeros(dr // 2, dtype=xr.dtype, device=xr.device)
+        be.rope_bwd(dout, xr, table, d_content, d_xr, d_if, B, S, H, dc, dr)
+        return d_content, d_xr, d_if, None
+
+
+class LatentMaskAttentionFn(Function):
+    """softmax(Q_h K_h^T / sqrt(hd) + M) V_h with M = W2 gelu(W1 (sum_h Q_h K_h^T) + b1) + b2 applied
+    along the key axis and shared by all heads (Vi_Tools:288-299).  q:[B,Sq,H*hd] k,v:[B,Skv,H*hd]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, w1, b1, w2, b2, u1, v1, s1, u2, v2, s2, H):
+        be = get_backend()
+        q, k, v = _c(q), _c(k), _c(v)
+        B, Sq, D = q.shape
+        Skv = k.shape[1]
+        hd = D // H
+        dev, dt = q.device, q.dtype
+        # raw all-head logits R = Q_all K_all^T
+        R = torch.empty(B, Sq, Skv, dtype=dt, device=dev)
+        be.gemm(q, k, R, Sq, Skv, D, (D, 1, Sq * D, 0), (D, 1, Skv * D, 0), (Skv, Sq * Skv, 0), batch=(B, 1))
+        # mask MLP along the key axis
+        R2 = R.view(B * Sq, Skv)
+        hp = torch.empty(B * Sq, w1.shape[0], dtype=dt, device=dev)
+        hg = torch.empty_like(hp)
+        _lin_fwd(be, R2, w1, s1, hg, bias=b1, act=ACT_GELU, pre=hp)
+        Mk = torch.empty(B * Sq, Skv, dtype=dt, device=dev)
+        _lin_fwd(be, hg, w2, s2, Mk, bias=b2)
+        # per-head logits + mask, softmax, PV
+        P = torch.empty(B, H, Sq, Skv, dtype=dt, device=dev)
+        scale = 1.0 / math.sqrt(hd)
+        be.gemm(q, k, P, Sq, Skv, hd, (D, 1, Sq * D, hd), (D, 1, Skv * D, hd), (Skv, H * Sq * Skv, Sq * Skv),
+                batch=(B, H), alpha=scale, residual=Mk, r=(Skv, Sq * Skv, 0))
+        be.softmax_fwd(P, B * H * Sq, Skv)
+        out = torch.empty(B, Sq, D, dtype=dt, device=dev)
+        be.gemm(P, v, out, Sq, hd, Skv, (Skv, 1, H * Sq * Skv, Sq * Skv), (1, D, Skv * D, hd), (D, Sq * D, hd),
+                batch=(B, H))
+        ctx.H = H
+        ctx.save_for_backward(q, k, v, R, hp, hg, P, w1, w2, u1, v1, s1, u2, v2, s2)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        be = get_backend()
+        q, k, v, R, hp, hg, P, w1, w2, u1, v1, s1, u2, v2, s2 = ctx.saved_tensors
+        H = ctx.H
+        B, Sq, D = q.shape
+        Skv = k.shape[1]
+        hd = D // H
+        scale = 1.0 / math.sqrt(hd)
+        dout = _c(dout)
+        dev, dt = q.device, q.dtype
+        pb = (H * Sq * Skv, Sq * Skv)
+        # dP = dO V^T ; dV = P^T dO
+        dP = torch.empty_like(P)
+        be.gemm(dout, v, dP, Sq, Skv, hd, (D, 1, Sq * D, hd), (D, 1, Skv * D, hd), (Skv,) + pb, batch=(B, H))
+        dv = torch.empty_like(v)
+        be.gemm(P, dout, dv, Skv, hd, Sq, (1, Skv) + pb, (1, D, Sq * D, hd), (D, Skv * D, hd), batch=(B, H))
+        be.softmax_bwd(P, dP, B * H * Sq, Skv)                 # dP now holds dL
+        dM = torch.empty(B * Sq, Skv, dtype=dt, device=dev)
+        be.sum_heads(dP, dM, B, H, Sq * Skv)
+        dq = torch.empty_like(q)
+        be.gemm(dP, k, dq, Sq, hd, Skv, (Skv, 1) + pb, (1, D, Skv * D, hd), (D, Sq * D, hd), batch=(B, H),
+                alpha=scale)
+        dk = torch.empty_like(k)
+        be.gemm(dP, q, dk, Skv, hd, Sq, (1, Skv) + pb, (1, D, Sq * D, hd), (D, Skv * D, hd), batch=(B, H),
+                alpha=scale)
+        # mask MLP backward
+        G2 = torch.empty_like(w2)
+        _lin_wgrad(be, dM, hg, G2)
+        dW2, _ = _sn_wbwd(be, G2, w2, u2, v2, s2)
+        db2 = _colsum(be, dM)
+        dhp = torch.empty_like(hp)
+        _lin_dgrad(be, dM, w2, s2, dhp, act=ACT_GELU_BWD, aux=hp)
+        R2 = R.view(B * Sq, Skv)
+        G1 = torch.empty_like(w1)
+        _lin_wgrad(be, dhp, R2, G1)
+        dW1, _ = _sn_wbwd(be, G1, w1, u1, v1, s1)
+        db1 = _colsum(be, dhp)
+        dR = torch.empty(B, Sq, Skv, dtype=dt, device=dev)
+        _lin_dgrad(be, dhp, w1, s1, dR.view(B * Sq, Skv))
+        # dQ_all += dR K_all ; dK_all += dR^T Q_all
+        be.gemm(dR, k, dq, Sq, D, Skv, (Skv, 1, Sq * Skv, 0), (1, D, Skv * D, 0), (D, Sq * D, 0), batch=(B, 1),
+                accumulate=True)
+        be.gemm(dR, q, dk, Skv, D, Sq, (1, Skv, Sq * Skv, 0), (1, D, Sq * D, 0), (D, Skv * D, 0), batch=(B, 1),
+                accumulate=True)
+        return dq, dk, dv, dW1, db1, dW2, db2, None, None, None, None, None, None, None
+
+
+class LatentFn(Function):
+    """(mean|raw) -> z = mean + eps*std, std = softplus(raw)+1e-6 (Vi_Tools:232-242) and this
+    tensor's KL term -0.5*mean(1 + 2 log std - mean^2 - std^2) (Vi_Tools:24-25)."""
+
+    @staticmethod
+    def forward(ctx, mv, noise):
+        be = get_backend()
+        mv = _c(mv)
+        mvh = mv.shape[-1] // 2
+        rows = mv.numel() // (2 * mvh)
+        z = torch.empty(mv.shape[:-1] + (mvh,), dtype=mv.dtype, device=mv.device)
+        std = torch.empty_like(z)
+        kl = torch.zeros((), dtype=mv.dtype, device=mv.device)
+        if noise is not None:
+            noise = _c(noise)
+        be.latent_fwd(mv, noise, z, std, kl, rows, mvh)
+        ctx.scale = -0.5 / z.numel()
+        kl.mul_(ctx.scale)
+        ctx.save_for_backward(mv, noise, std)
+        ctx.mark_non_differentiable(std)
+        return z, std, kl
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dz, _dstd, dkl):
+        be = get_backend()
+        mv, noise, std = ctx.saved_tensors
+        mvh = mv.shape[-1] // 2
+        rows = mv.numel() // (2 * mvh)
+        dks = (dkl * ctx.scale).reshape(1).contiguous() if dkl is not None else None
+        dz = _c(dz) if dz is not None else None
+        dmv = torch.empty_like(mv)
+        be.latent_bwd(dz, dks, mv, noise, std, dmv, rows, mvh)
+        return dmv, None
+
+
+class AddFn(Function):
+    """Residual / U-net skip adds (Vi_Tools:309,315,403,513-522) and the latent running sum (43-44)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        be = get_backend()
+        a, b = _c(a), _c(b)
+        out = torch.empty_like(a)
+        be.add(a, b, out, a.numel())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
+class ImageToRowsFn(Function):
+    """[B,3,S,S] -> [B,S,3S] (Vi_Tools:389-391)."""
+
+    @staticmethod
+    def forward(ctx, img):
+        be = get_backend()
+        img = _c(img)
+        B, Cc, S, S2 = img.shape
+        assert Cc == 3 and S == S2, "row tokenisation expects [B,3,S,S]"
+        rows = torch.empty(B, S, 3 * S, dtype=img.dtype, device=img.device)
+        be.image_to_rows(img, rows, B, S)
+        ctx.dims = (B, S)
+        return rows
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        be = get_backend()
+        B, S = ctx.dims
+        g = _c(g)
+        img = torch.empty(B, 3, S, S, dtype=g.dtype, device=g.device)
+        be.rows_to_image(g, img, B, S)
+        return img
+
+
+class GridTransposeFn(Function):
+    """rows <-> columns of the [B,S,S,3] token grid (Vi_Tools:394-395,397-398); self-inverse."""
+
+    @staticmethod
+    def forward(ctx, x):
+        be = get_backend()
+        x = _c(x)
+        B, S, W = x.shape
+        assert W == 3 * S, "token grid must be [B,S,3S]"
+        out = torch.empty_like(x)
+        be.grid_transpose(x, out, B, S)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        be = get_backend()
+        g = _c(g)
+        B, S, _ = g.shape
+        out = torch.empty_like(g)
+        be.grid_transpose(g, out, B, S)
+        return out
+
+
+class MeanSeqFn(Function):
+    """AdaptiveAvgPool1d(1) over the sequence (CALM_ViT_V2.py:74-75)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        be = get_backend()
+        x = _c(x)
+        B, S, D = x.shape
+        y = torch.empty(B, D, dtype=x.dtype, device=x.device)
+        be.mean_seq_fwd(x, y, B, S, D)
+        ctx.dims = (B, S, D)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        be = get_backend()
+        B, S, D = ctx.dims
+        g = _c(g)
+        dx = torch.empty(B, S, D, dtype=g.dtype, device=g.device)
+        be.mean_seq_bwd(g, dx, B, S, D)
+        return dx
+
+
+class CnnResidualFn(Function):
+    """x + conv1x1(32->3)(gelu(dw3x3(gelu(conv1x1(3->32)(x))))) on the token grid as a channels-last
+    image (Vi_Tools:378-385,400-403; CALM_ViT_V2.py:60-67,80-83).  The 1x1 convs are pixel GEMMs."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w2, b2, w4, b4, u0, v0, s0, u2, v2, s2, u4, v4, s4):
+        be = get_backend()
+        x = _c(x)
+        B, S, W = x.shape
+        Ch = w0.shape[0]
+        npix = B * S * S
+        dev, dt = x.device, x.dtype
+        xp = x.view(npix, 3)
+        h1p = torch.empty(npix, Ch, dtype=dt, device=dev)
+        h1 = torch.empty_like(h1p)
+        _lin_fwd(be, xp, w0.view(Ch, 3), s0, h1, bias=b0, act=ACT_GELU, pre=h1p)
+        h2p = torch.empty_like(h1p)
+        h2 = torch.empty_like(h1p)
+        be.dwconv_fwd(h1, w2, s2, b2, h2, h2p, ACT_GELU, B, S, Ch)
+        out = torch.empty_like(x)
+        _lin_fwd(be, h2, w4.view(3, Ch), s4, out.view(npix, 3), bias=b4, residual=xp)
+        ctx.dims = (B, S, Ch)
+        ctx.save_for_backward(xp, h1p, h1, h2p, h2, w0, w2, w4, u0, v0, s0, u2, v2, s2, u4, v4, s4)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        be = get_backend()
+        xp, h1p, h1, h2p, h2, w0, w2, w4, u0, v0, s0, u2, v2, s2, u4, v4, s4 = ctx.saved_tensors
+        B, S, Ch = ctx.dims
+        npix = B * S * S
+        dy = _c(dy)
+        dyp = dy.view(npix, 3)
+        w0m, w4m = w0.view(Ch, 3), w4.view(3, Ch)
+        G4 = torch.empty_like(w4m)
+        _lin_wgrad(be, dyp, h2, G4)
+        dW4, _ = _sn_wbwd(be, G4, w4m, u4, v4, s4)
+        db4 = _colsum(be, dyp)
+        dh2p = torch.empty_like(h2p)
+        _lin_dgrad(be, dyp, w4m, s4, dh2p, act=ACT_GELU_BWD, aux=h2p)
+        dh1 = torch.empty_like(h1)
+        G2 = torch.zeros(Ch, 9, dtype=dy.dtype, device=dy.device)
+        db2 = torch.zeros(Ch, dtype=dy.dtype, device=dy.device)
+        be.dwconv_bwd(dh2p, h1, w2, s2, dh1, G2, db2, B, S, Ch)
+        dW2, _ = _sn_wbwd(be, G2, w2.view(Ch, 9), u2, v2, s2)
+        dh1p = dh2p                                            # reuse the buffer
+        be.gelu_bwd(dh1, h1p, dh1p, dh1.numel())
+        G0 = torch.empty_like(w0m)
+        _lin_wgrad(be, dh1p, xp, G0)
+        dW0, _ = _sn_wbwd(be, G0, w0m, u0, v0, s0)
+        db0 = _colsum(be, dh1p)
+        dx = torch.empty_like(dy)
+        _lin_dgrad(be, dh1p, w0m, s0, dx.view(npix, 3), residual=dyp)
+        return (dx, dW0.view_as(w0), db0, dW2.view_as(w2), db2, dW4.view_as(w4), db4,
+                None, None, None, None, None, None, None, None, None)
+
+
+# ---------------------------------------------------------------------------------------
+# functional front-ends
+# ---------------------------------------------------------------------------------------
+def layer_norm(x, w, eps=1e-6):
+    return LayerNormFn.apply(x, w, eps)
+
+
+def add(a, b):
+    return AddFn.apply(a, b)
+
+
+def image_to_rows(img):
+    return ImageToRowsFn.apply(img)
+
+
+def grid_transpose(x):
+    return GridTransposeFn.apply(x)
+
+
+def mean_seq(x):
+    return MeanSeqFn.apply(x)

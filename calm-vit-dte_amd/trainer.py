@@ -1,0 +1,195 @@
+"""Per-rank training step and single-node data parallelism for the CALM-ViT path.
+
+Replaces the Spark TorchDistributor launcher + DDP wrapper of
+/root/reference/CALM-ViT/distributed_trainer_cls.py (train(): 25-114, __main__: 116-175) with
+torch.distributed over RCCL (one process per GPU, env:// rendezvous from RANK/LOCAL_RANK/WORLD_SIZE
+as set by torchrun):
+
+  * `init_distributed()`               <- dist.init_process_group(...)                 (cls:46-51)
+  * `sync_module_states(model)`        <- DDP ctor broadcast of params+buffers         (cls:55)
+  * `BucketedGradReducer`              <- DDP's bucketed gradient all-reduce           (cls:55,87):
+        gradients are packed into a few large flat buckets (sized for xGMI: point-to-point links,
+        per-link-bound rings -> fewer, larger collectives) as soon as backward has produced them, and
+        all-reduced (mean) on a SIDE HIP stream while the rest of backward keeps running.
+  * `TrainStep`                        <- one iteration of the step loop               (cls:79-96):
+        forward, CE with soft targets, backward, unscale / clip_grad_norm_(1.0), AdamW, zero_grad.
+
+The model also works under stock `torch.nn.parallel.DistributedDataParallel` (that is what the
+reference's train() does with it); the reducer here is the MI355X-tuned equivalent.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(use_gpu=True):
+    """Returns (rank, local_rank, world_size).  No-op (0,0,1) when not launched by torchrun."""
+    if int(os.environ.get("WORLD_SIZE", "1")) <= 1:
+        return 0, 0, 1
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    local_rank = int(os.environ.get("LOCAL_RANK", rank))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not dist.is_initialized():
+        if use_gpu:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo")
+    return rank, local_rank, world
+
+
+def _flat_groups(tensors, max_bytes):
+    groups, cur, size = [], [], 0
+    for t in tensors:
+        nb = t.numel() * t.element_size()
+        if cur and size + nb > max_bytes:
+            groups.append(cur)
+            cur, size = [], 0
+        cur.append(t)
+        size += nb
+    if cur:
+        groups.append(cur)
+    return groups
+
+
+@torch.no_grad()
+def sync_module_states(model, src=0, bucket_bytes=256 << 20):
+    """Broadcast parameters and buffers from rank `src` (what DDP's constructor does)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return
+    tensors = [p.data for p in model.parameters()] + [b.data for b in model.buffers()]
+    by_type = {}
+    for t in tensors:
+        by_type.setdefault((t.dtype, t.device), []).append(t)
+    for group in by_type.values():
+        for chunk in _flat_groups(group, bucket_bytes):
+            flat = torch.cat([t.reshape(-1) for t in chunk])
+            dist.broadcast(flat, src)
+            off = 0
+            for t in chunk:
+                t.copy_(flat[off:off + t.numel()].view_as(t))
+                off += t.numel()
+
+
+class BucketedGradReducer:
+    """Mean all-reduce of all gradients in large flat buckets, overlapped with backward.
+
+    Parameters are bucketed in reverse registration order (~ the order backward produces their
+    gradients).  When the last gradient of a bucket has been accumulated, the bucket is packed and its
+    all-reduce is launched on a side stream (RCCL over xGMI on the GPU; gloo on CPU in tests).
+    `finish()` (call after backward) waits for the collectives and scatters the means back into
+    `p.grad`."""
+
+    def __init__(self, model, bucket_mb=64, process_group=None):
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.enabled = self.world > 1
+        self.buckets = []
+        self._works = []
+        if not self.enabled:
+            return
+        dev = self.params[0].device
+        self.on_gpu = dev.type == "cuda"
+        self.side = torch.cuda.Stream(device=dev) if self.on_gpu else None
+        for group in _flat_groups(list(reversed(self.params)), bucket_mb << 20):
+            n = sum(p.numel() for p in group)
+            flat = torch.zeros(n, dtype=group[0].dtype, device=dev)
+            views, off = [], 0
+            for p in group:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            self.buckets.append({"params": group, "flat": flat, "views": views, "pending": len(group)})
+        self._where = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b["params"]:
+                self._where[p] = bi
+                p.register_post_accumulate_grad_hook(self._hook)
+
+    def _hook(self, p):
+        b = self.buckets[self._where[p]]
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            self._launch(b)
+
+    def _launch(self, b):
+        grads = [p.grad for p in b["params"]]
+        if self.on_gpu:
+            self.side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.side):
+                torch._foreach_copy_(b["views"], grads)
+                work = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        else:
+            torch._foreach_copy_(b["views"], grads)
+            work = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        self._works.append((work, b))
+
+    @torch.no_grad()
+    def finish(self):
+        if not self.enabled:
+            return
+        for b in self.buckets:                      # bucket not launched by the hooks: some of its
+            if b["pending"] > 0:                    # parameters got no gradient this step
+                for p in b["params"]:
+                    if p.grad is None:
+                        p.grad = torch.zeros_like(p)
+                self._launch(b)
+        inv = 1.0 / self.world
+        for work, b in self._works:
+            if self.on_gpu:
+                with torch.cuda.stream(self.side):
+                    work.wait()                     # side stream waits for RCCL; the host does not block
+                    torch._foreach_mul_(b["views"], inv)
+                    torch._foreach_copy_([p.grad for p in b["params"]], b["views"])
+            else:
+                work.wait()
+                torch._foreach_mul_(b["views"], inv)
+                torch._foreach_copy_([p.grad for p in b["params"]], b["views"])
+        if self.on_gpu:
+            torch.cuda.current_stream().wait_stream(self.side)
+        self._works.clear()
+        for b in self.buckets:
+            b["pending"] = len(b["params"])
+
+
+def soft_target_cross_entropy(logits, soft_targets):
+    """torch.nn.CrossEntropyLoss() with class-probability targets (cls:63,86; CutMix/MixUp labels)."""
+    return torch.nn.functional.cross_entropy(logits, soft_targets)
+
+
+class TrainStep:
+    """One iteration of distributed_trainer_cls.py:79-96 (per rank)."""
+
+    def __init__(self, model, optimizer, reducer=None, max_norm=1.0, scaler=None):
+        self.model, self.opt, self.reducer = model, optimizer, reducer
+        self.max_norm = max_norm
+        self.scaler = scaler
+        self.params = [p for p in model.parameters() if p.requires_grad]
+
+    def __call__(self, x, y_soft):
+        y_hat, _ = self.model(x)                                           # cls:85
+        loss = soft_target_cross_entropy(y_hat.squeeze(), y_soft)          # cls:86
+        if self.scaler is not None:
+            self.scaler.scale(loss).backward()                             # cls:87
+        else:
+            loss.backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        if self.scaler is not None:
+            self.scaler.unscale_(self.opt)                                 # cls:88
+        torch.nn.utils.clip_grad_norm_(self.params, max_norm=self.max_norm, error_if_nonfinite=False)   # cls:92
+        if self.scaler is not None:
+            self.scaler.step(self.opt)                                     # cls:93-94
+            self.scaler.update()
+        else:
+            self.opt.step()
+        self.opt.zero_grad()                                               # cls:96
+        return loss.detach(), y_hat.detach()
+
+
+def make_optimizer(model, lr=3.1e-3, weight_decay=0.02, betas=(0.9, 0.98)):
+    """optim.AdamW(model.parameters(), lr=3.1e-3, weight_decay=0.02, betas=(0.9, 0.98)) (cls:146,158)."""
+    params = [p for p in model.parameters() if p.requires_grad]
+    fused = params[0].is_cuda
+    return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=betas, fused=fused)

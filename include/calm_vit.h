@@ -1,0 +1,211 @@
+/*
+ * calm_vit.h — C-ABI of libcalmvit_hip.so, the MI355X (gfx950) kernel library behind the
+ * CALM-ViT cross-axial latent-masking attention path.
+ *
+ * The reference (focegueda1998/CALM-ViT-DTE) is pure Python: its "FFI" for this path is the
+ * set of ATen ops that CALM-ViT/Vi_Tools_CNN_less_V2.py and CALM-ViT/CALM_ViT_V2.py call.
+ * Each entry point below replaces one such call site (cited as file:line into
+ * /root/reference/CALM-ViT/) and is bound from Python with ctypes
+ * (calm-vit-dte_amd/_lib.py; see INTEGRATION.md for the reference-side stub).
+ *
+ * Conventions
+ *  - plain device pointers + sizes; element strides unless stated; no torch types.
+ *  - every call only ENQUEUES work on `stream` (hipStream_t passed as void*): no allocation,
+ *    no host synchronisation, re-entrant, hipGraph-capturable.
+ *  - return value: 0 = ok, <0 = invalid argument / unsupported shape (CALM_E_*),
+ *    >0 = hipError_t of the failed launch.  No C++ exceptions cross the boundary.
+ *  - NaN/Inf propagate (GradScaler's inf check relies on it, distributed_trainer_cls.py:88,93).
+ *  - dtype of all tensors in this revision: fp32 (CALM_F32).
+ */
+#ifndef CALM_VIT_H
+#define CALM_VIT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CALM_ABI_VERSION 1
+
+#define CALM_E_INVAL   (-1)   /* null pointer / negative size                 */
+#define CALM_E_LAYOUT  (-2)   /* stride pattern the kernel cannot address     */
+#define CALM_E_UNSUPP  (-3)   /* combination of options not implemented       */
+
+enum { CALM_F32 = 0 };
+enum { CALM_ACT_NONE = 0, CALM_ACT_GELU = 1, CALM_ACT_GELU_BWD = 2 };
+
+int         calm_abi_version(void);
+const char* calm_build_info(void);     /* "gfx950 ..." */
+
+/* ---------------------------------------------------------------------------------------
+ * Strided, batched GEMM with fused epilogue on the matrix cores (v_mfma_f32_32x32x2_f32).
+ *
+ *   acc(m,n)  = sum_k A(m,k) * B(n,k)                 A(m,k) = A[m*a_rs + k*a_cs + b0*a_b0 + b1*a_b1]
+ *   z         = acc * alpha / (inv_scale ? *inv_scale : 1) + (bias ? bias[n] : 0)
+ *   C_pre(m,n)= z                                      (optional second output, C's layout)
+ *   y         = act == GELU      ? gelu_erf(z)
+ *             : act == GELU_BWD  ? z * gelu_erf'(aux(m,n))   (aux: C's layout)
+ *             : z
+ *   C(m,n)    = y * (col_scale ? col_scale[n] : 1) + (residual ? residual(m,n) : 0) [+ C(m,n) if accumulate]
+ *
+ * One of (a_rs, a_cs) must be 1, likewise (b_rs, b_cs); C is n-contiguous.
+ * batch = batch0*batch1 independent problems (b0,b1 strides per operand; 0 = broadcast).
+ * reduce_batch: all batches are summed into ONE C (c_b0/c_b1 ignored) — the weight gradient of
+ * the sequence-axis linears.  split_k: 0 = library picks, 1 = off, >1 = that many K-slices; slices
+ * and reduce_batch combine through fp32 atomics and then allow alpha/inv_scale only.
+ *
+ * Replaces: nn.Linear / matmul / bmm call sites Vi_Tools_CNN_less_V2.py:226-231, 251-267, 276-277,
+ * 288-290 (raw QK^T + linear_mask), 293-298 (QK^T, PV of SDPA), 300, 305-308, 312;
+ * CALM_ViT_V2.py:76 (head), 1x1 convs Vi_Tools:380,384 — and all their autograd backward GEMMs.
+ * ------------------------------------------------------------------------------------- */
+typedef struct calm_gemm_args {
+    const void* A; const void* B; void* C;
+    int32_t M, N, K;
+    int32_t batch0, batch1;
+    int64_t a_rs, a_cs, a_b0, a_b1;
+    int64_t b_rs, b_cs, b_b0, b_b1;
+    int64_t c_rs, c_b0, c_b1;
+    float        alpha;
+    const float* inv_scale;      /* device scalar (spectral-norm sigma) or NULL */
+    const float* bias;           /* [N] or NULL */
+    const float* col_scale;      /* [N] or NULL (LayerScale ls_att / ls_mlp) */
+    const void*  residual; int64_t r_rs, r_b0, r_b1;
+    void*        C_pre;          /* optional pre-activation output */
+    const void*  aux;            /* GELU_BWD: saved pre-activation */
+    int32_t act;
+    int32_t accumulate;
+    int32_t reduce_batch;
+    int32_t split_k;
+    int32_t dtype;
+} calm_gemm_args;
+
+int calm_gemm(const calm_gemm_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * LayerNorm(D, eps, bias=False) over the last axis (Vi_Tools:131-132,197,494; fwd 211-215,311,523).
+ * x,y: [rows, D] contiguous.  mean,rstd: [rows] saved for backward.
+ * bwd: dx = rstd*(w*dy - mean_D(w*dy) - xhat*mean_D(w*dy*xhat)); dw[D] += sum_rows dy*xhat
+ * (dw must be zeroed by the caller; accumulated with atomics).
+ * ------------------------------------------------------------------------------------- */
+int calm_layernorm_fwd(const float* x, const float* w, float* y, float* mean, float* rstd,
+                       int64_t rows, int32_t D, float eps, void* stream);
+int calm_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean,
+                       const float* rstd, float* dx, float* dw, int64_t rows, int32_t D, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Learned-frequency NeoX RoPE + head assembly (Vi_Tools:80-95 applied at 275-285).
+ * out[b,s,h, 0:dc]      = content[b,s,h,:]               (dc may be 0: plain blocks)
+ * out[b,s,h, dc:dc+dr]  = rope(xr[b,s,h,:], t=s, inv_freq[dr/2])
+ * content: [B,S,H,dc], xr: [B,S,H,dr], out: [B,S,H,dc+dr], all contiguous.
+ * table: [2, S, dr/2] workspace; fwd fills it with cos|sin(t * inv_freq) (rebuilt every forward
+ * because inv_freq is a learned parameter, Vi_Tools:70-71,86-91) and bwd reads it back.
+ * bwd: d_content, d_xr from d_out; d_inv_freq[dr/2] += ... (atomics; caller zeroes).
+ * ------------------------------------------------------------------------------------- */
+int calm_rope_fwd(const float* content, const float* xr, const float* inv_freq, float* table, float* out,
+                  int32_t B, int32_t S, int32_t H, int32_t dc, int32_t dr, void* stream);
+int calm_rope_bwd(const float* d_out, const float* xr, const float* table,
+                  float* d_content, float* d_xr, float* d_inv_freq,
+                  int32_t B, int32_t S, int32_t H, int32_t dc, int32_t dr, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Row softmax of the masked logits and its backward (the softmax inside
+ * F.scaled_dot_product_attention, Vi_Tools:293-298).  In place.  rows x cols contiguous.
+ * bwd: dp <- p * (dp - sum_j p*dp).
+ * calm_sum_heads: dm[b,i,j] = sum_h dl[b,h,i,j]  (gradient of the head-broadcast mask, :291).
+ * ------------------------------------------------------------------------------------- */
+int calm_softmax_fwd(float* x, int64_t rows, int32_t cols, void* stream);
+int calm_softmax_bwd(const float* p, float* dp, int64_t rows, int32_t cols, void* stream);
+int calm_sum_heads(const float* dl, float* dm, int32_t B, int32_t H, int64_t per_head, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Latent bottleneck sampling (Vi_Tools:232-242) + KL partial sum (Vi_Tools:24-25).
+ * mv: [rows, 2*mvh] (mean | raw).  std = softplus(raw)+1e-6;  z = mean + noise*std (noise NULL
+ * in eval: z = mean).  kl_sum (device scalar, caller zeroes) += sum(1 + 2 log std - mean^2 - std^2).
+ * bwd: dmv from dz and the scalar d(kl_sum) (device pointer).
+ * ------------------------------------------------------------------------------------- */
+int calm_latent_fwd(const float* mv, const float* noise, float* z, float* std_out, float* kl_sum,
+                    int64_t rows, int32_t mvh, void* stream);
+int calm_latent_bwd(const float* dz, const float* d_kl_sum, const float* mv, const float* noise,
+                    const float* std_in, float* dmv, int64_t rows, int32_t mvh, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Spectral norm (hook-based torch.nn.utils.spectral_norm wrapped around every Linear/Conv:
+ * Vi_Tools:137-205,380-384; CALM_ViT_V2.py:50-52,62-66), batched over a table of layers.
+ * training!=0: v <- normalize(W^T u); u <- normalize(W v); sigma = u.(W v)   (in place on u,v)
+ * training==0: sigma = u.(W v) with the stored u,v.
+ * Three launches cover ALL layers of the model (the reference issues 882 mv + 883 div per forward).
+ *
+ * Usage: fill a host array of calm_sn_layer (device pointers inside), call calm_sn_plan() to get
+ * the size of / fill a host "plan" blob, copy the blob to device memory once (pointers must stay
+ * valid), then call calm_sn_power_iter(plan_dev, ...) every step with `scratch` of
+ * plan_info.scratch_floats floats.
+ * ------------------------------------------------------------------------------------- */
+typedef struct calm_sn_layer {
+    const float* w;      /* [rows, cols] row-major (conv weights flattened over dim 0) */
+    float* u;            /* [rows] */
+    float* v;            /* [cols] */
+    float* sigma;        /* [1] */
+    int32_t rows, cols;
+} calm_sn_layer;
+
+typedef struct calm_sn_plan_info {
+    int64_t blob_bytes;      /* size of the plan blob */
+    int64_t scratch_floats;  /* size of the per-call scratch */
+    int32_t n_layers, n_work;
+} calm_sn_plan_info;
+
+/* blob_host == NULL: only fills *info.  Otherwise writes blob_bytes bytes to blob_host. */
+int calm_sn_plan(const calm_sn_layer* layers, int32_t n, void* blob_host, calm_sn_plan_info* info);
+int calm_sn_power_iter(const void* plan_dev, const calm_sn_plan_info* info, int32_t training,
+                       float eps, float* scratch, void* stream);
+
+/* Weight gradient through W = W_orig / sigma (and an optional LayerScale on the output):
+ *   d_ls[c]  = sum_k G[c,k] * W_orig[c,k] / sigma            (only if ls != NULL; written)
+ *   G0       = (ls ? ls[c] : 1) * G
+ *   dW_orig  = (G0 - <G0, W_orig/sigma> u v^T) / sigma       (written)
+ * G: [rows, cols] = dY^T X.  scratch: >= rows+2 floats. */
+int calm_sn_weight_bwd(const float* G, const float* w_orig, const float* u, const float* v,
+                       const float* sigma, const float* ls, float* d_w_orig, float* d_ls,
+                       int32_t rows, int32_t cols, float* scratch, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Tokenisation (bit-exact index work).
+ * image_to_rows : rows[b,i,3j+c] = img[b,c,i,j]           (Vi_Tools:389-391); rows_to_image inverse.
+ * grid_transpose: out[b,j,3i+c]  = in[b,i,3j+c]           (Vi_Tools:394-395,397-398; self-inverse)
+ * ------------------------------------------------------------------------------------- */
+int calm_image_to_rows(const float* img, float* rows, int32_t B, int32_t S, void* stream);
+int calm_rows_to_image(const float* rows, float* img, int32_t B, int32_t S, void* stream);
+int calm_grid_transpose(const float* in, float* out, int32_t B, int32_t S, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Depthwise 3x3 conv (padding 1, zeros) + bias on a channels-last [B,S,S,C] grid
+ * (middle layer of Block.proj, Vi_Tools:382; CALM_ViT_V2.py:64).  w: [C,3,3], bias: [C].
+ * act: CALM_ACT_NONE/GELU; y_pre (optional) receives the pre-activation.
+ * bwd: dx from dz (gradient wrt the pre-activation); dw[C,9], db[C] accumulated (caller zeroes).
+ * ------------------------------------------------------------------------------------- */
+int calm_dwconv3x3_fwd(const float* x, const float* w, const float* inv_scale, const float* bias,
+                       float* y, float* y_pre, int32_t act, int32_t B, int32_t S, int32_t C, void* stream);
+int calm_dwconv3x3_bwd(const float* dz, const float* x, const float* w, const float* inv_scale,
+                       float* dx, float* dw, float* db, int32_t B, int32_t S, int32_t C, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Small streaming helpers.
+ * add          : out = a + b                         (residual / U-net skips, Vi_Tools:309,315,403,513-522)
+ * gelu_bwd     : dz = dy * gelu'(z)                  (where it is not fused into a GEMM epilogue)
+ * colsum       : out[n] += sum_m x[m,n]              (bias gradients; caller zeroes)
+ * row_scale    : out[r,c] = x[r,c] * s[r]            (ls-scaled weight for the dgrad of out_proj/mlp.3)
+ * mean_seq     : y[b,d] = mean_s x[b,s,d]            (AdaptiveAvgPool1d, CALM_ViT_V2.py:74-75) and bwd
+ * ------------------------------------------------------------------------------------- */
+int calm_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+int calm_gelu_bwd(const float* dy, const float* z, float* dz, int64_t n, void* stream);
+int calm_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* stream);
+int calm_row_scale(const float* x, const float* s, float* out, int32_t rows, int32_t cols, void* stream);
+int calm_mean_seq_fwd(const float* x, float* y, int32_t B, int32_t S, int32_t D, void* stream);
+int calm_mean_seq_bwd(const float* dy, float* dx, int32_t B, int32_t S, int32_t D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CALM_VIT_H */

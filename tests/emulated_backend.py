@@ -1,0 +1,227 @@
+"""TEST INFRASTRUCTURE: a plain-torch emulation of every entry point of include/calm_vit.h, with
+the same argument meaning (strides, in-place outputs, accumulate semantics).  Two uses:
+  * CPU (-m "not gpu"): run the package's autograd plumbing (ops.py, modules) without a GPU and
+    compare with the oracle / golden fixtures -> validates the host logic.
+  * GPU (-m gpu): per-kernel parity of the HIP library against this emulation on the same inputs.
+It is never imported by the package.
+"""
+import math
+
+import torch
+
+ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
+
+
+def _gelu(x):
+    return 0.5 * x * (1.0 + torch.erf(x / math.sqrt(2.0)))
+
+
+def _gelu_grad(x):
+    return 0.5 * (1.0 + torch.erf(x / math.sqrt(2.0))) + x * torch.exp(-0.5 * x * x) / math.sqrt(2 * math.pi)
+
+
+def _view(t, sizes, strides):
+    return torch.as_strided(t, sizes, strides, t.storage_offset())
+
+
+class EmuPlan:
+    def __init__(self, layers):
+        self.layers = layers
+        self.key = tuple(x.data_ptr() for l in layers for x in l)
+
+
+class EmulatedBackend:
+    name = "emulated"
+
+    def gemm(self, A, B, Cout, M, N, K, a, b, c, batch=(1, 1), alpha=1.0, inv_scale=None, bias=None,
+             col_scale=None, residual=None, r=(0, 0, 0), C_pre=None, aux=None, act=ACT_NONE,
+             accumulate=False, reduce_batch=False, split_k=0):
+        b0, b1 = batch
+        Av = _view(A, (b0, b1, M, K), (a[2], a[3], a[0], a[1]))
+        Bv = _view(B, (b0, b1, N, K), (b[2], b[3], b[0], b[1]))
+        acc = torch.matmul(Av, Bv.transpose(-1, -2))
+        scale = alpha / inv_scale if inv_scale is not None else alpha
+        if reduce_batch:
+            acc = acc.sum(dim=(0, 1), keepdim=True)
+            Cv = _view(Cout, (1, 1, M, N), (0, 0, c[0], 1))
+            z = acc * scale
+            assert bias is None and col_scale is None and residual is None and C_pre is None and act == 0
+            Cv.copy_(Cv + z if accumulate else z)
+            return
+        Cv = _view(Cout, (b0, b1, M, N), (c[1], c[2], c[0], 1))
+        z = acc * scale
+        if bias is not None:
+            z = z + bias
+        if C_pre is not None:
+            _view(C_pre, (b0, b1, M, N), (c[1], c[2], c[0], 1)).copy_(z)
+        if act == ACT_GELU:
+            z = _gelu(z)
+        elif act == ACT_GELU_BWD:
+            z = z * _gelu_grad(_view(aux, (b0, b1, M, N), (c[1], c[2], c[0], 1)))
+        if col_scale is not None:
+            z = z * col_scale
+        if residual is not None:
+            z = z + _view(residual, (b0, b1, M, N), (r[1], r[2], r[0], 1))
+        if accumulate:
+            z = z + Cv
+        Cv.copy_(z)
+
+    def layernorm_fwd(self, x, w, y, mean, rstd, rows, D, eps):
+        x2 = x.reshape(rows, D)
+        mu = x2.mean(dim=1)
+        var = ((x2 - mu[:, None]) ** 2).mean(dim=1)
+        rs = torch.rsqrt(var + eps)
+        y.view(rows, D).copy_((x2 - mu[:, None]) * rs[:, None] * w)
+        mean.copy_(mu)
+        rstd.copy_(rs)
+
+    def layernorm_bwd(self, dy, x, w, mean, rstd, dx, dw, rows, D):
+        x2, g2 = x.reshape(rows, D), dy.reshape(rows, D)
+        xh = (x2 - mean[:, None]) * rstd[:, None]
+        g = g2 * w
+        c1 = g.mean(dim=1, keepdim=True)
+        c2 = (g * xh).mean(dim=1, keepdim=True)
+        dx.view(rows, D).copy_(rstd[:, None] * (g - c1 - xh * c2))
+        dw.add_((g2 * xh).sum(dim=0))
+
+    @staticmethod
+    def _table(inv_freq, S):
+        t = torch.arange(S, dtype=torch.float32, device=inv_freq.device)
+        ang = torch.outer(t, inv_freq)
+        return ang.cos(), ang.sin()
+
+    def rope_fwd(self, content, xr, inv_freq, table, out, B, S, H, dc, dr):
+        half = dr // 2
+        cos, sin = self._table(inv_freq, S)
+        table.view(2, S, half)[0].copy_(cos)
+        table.view(2, S, half)[1].copy_(sin)
+        x = xr.view(B, S, H, dr)
+        o = out.view(B, S, H, dc + dr)
+        if dc:
+            o[..., :dc] = content.view(B, S, H, dc)
+        c, s = cos[None, :, None, :], sin[None, :, None, :]
+        x1, x2 = x[..., :half], x[..., half:]
+        o[..., dc:dc + half] = x1 * c - x2 * s
+        o[..., dc + half:] = x2 * c + x1 * s
+
+    def rope_bwd(self, d_out, xr, table, d_content, d_xr, d_inv_freq, B, S, H, dc, dr):
+        half = dr // 2
+        cos, sin = table.view(2, S, half)[0], table.view(2, S, half)[1]
+        g = d_out.view(B, S, H, dc + dr)
+        x = xr.view(B, S, H, dr)
+        if dc:
+            d_content.view(B, S, H, dc).copy_(g[..., :dc])
+        c, s = cos[None, :, None, :], sin[None, :, None, :]
+        g1, g2 = g[..., dc:dc + half], g[..., dc + half:]
+        x1, x2 = x[..., :half], x[..., half:]
+        dx = d_xr.view(B, S, H, dr)
+        dx[..., :half] = g1 * c + g2 * s
+        dx[..., half:] = g2 * c - g1 * s
+        dang = g1 * (-x1 * s - x2 * c) + g2 * (-x2 * s + x1 * c)
+        t = torch.arange(S, dtype=torch.float32, device=xr.device)[None, :, None, None]
+        d_inv_freq.add_((dang * t).sum(dim=(0, 1, 2)))
+
+    def softmax_fwd(self, x, rows, cols):
+        v = x.view(rows, cols)
+        v.copy_(torch.softmax(v, dim=1))
+
+    def softmax_bwd(self, p, dp, rows, cols):
+        pv, gv = p.view(rows, cols), dp.view(rows, cols)
+        s = (pv * gv).sum(dim=1, keepdim=True)
+        gv.copy_(pv * (gv - s))
+
+    def sum_heads(self, dl, dm, B, H, per_head):
+        dm.view(B, per_head).copy_(dl.view(B, H, per_head).sum(dim=1))
+
+    def latent_fwd(self, mv, noise, z, std, kl_sum, rows, mvh):
+        m2 = mv.reshape(rows, 2 * mvh)
+        mean, raw = m2[:, :mvh], m2[:, mvh:]
+        sd = torch.nn.functional.softplus(raw) + 1e-6
+        zz = mean if noise is None else mean + noise.reshape(rows, mvh) * sd
+        z.view(rows, mvh).copy_(zz)
+        std.view(rows, mvh).copy_(sd)
+        kl_sum.add_((1 + 2 * torch.log(sd) - mean * mean - sd * sd).sum())
+
+    def latent_bwd(self, dz, d_kl_sum, mv, noise, std, dmv, rows, mvh):
+        m2 = mv.reshape(rows, 2 * mvh)
+        mean, raw = m2[:, :mvh], m2[:, mvh:]
+        sd = std.reshape(rows, mvh)
+        g = dz.reshape(rows, mvh) if dz is not None else torch.zeros_like(sd)
+        dk = d_kl_sum.reshape(()) if d_kl_sum is not None else 0.0
+        dmean = g - 2.0 * dk * mean
+        dstd = dk * (2.0 / sd - 2.0 * sd)
+        if noise is not None:
+            dstd = dstd + g * noise.reshape(rows, mvh)
+        out = dmv.view(rows, 2 * mvh)
+        out[:, :mvh] = dmean
+        out[:, mvh:] = dstd * torch.sigmoid(raw)
+
+    def sn_plan(self, layers):
+        return EmuPlan(layers)
+
+    def sn_power_iter(self, plan, training):
+        eps = 1e-12
+        for w, u, v, sigma in plan.layers:
+            if training:
+                t = w.t().mv(u)
+                v.copy_(t / t.norm().clamp_min(eps))
+                s = w.mv(v)
+                u.copy_(s / s.norm().clamp_min(eps))
+                sigma.copy_(torch.dot(u, s).reshape(1))
+            else:
+                sigma.copy_(torch.dot(u, w.mv(v)).reshape(1))
+
+    def sn_weight_bwd(self, G, w, u, v, sigma, ls, dW, d_ls, rows, cols):
+        G2, w2 = G.reshape(rows, cols), w.reshape(rows, cols)
+        rowdot = (G2 * w2).sum(dim=1) / sigma
+        lsv = ls if ls is not None else torch.ones_like(rowdot)
+        dot = (lsv * rowdot).sum()
+        dW.view(rows, cols).copy_((lsv[:, None] * G2 - dot * torch.outer(u, v)) / sigma)
+        if d_ls is not None:
+            d_ls.copy_(rowdot)
+
+    def image_to_rows(self, img, rows, B, S):
+        rows.copy_(img.permute(0, 2, 3, 1).reshape(B, S, 3 * S))
+
+    def rows_to_image(self, rows, img, B, S):
+        img.copy_(rows.view(B, S, S, 3).permute(0, 3, 1, 2))
+
+    def grid_transpose(self, x, out, B, S):
+        out.copy_(x.view(B, S, S, 3).permute(0, 2, 1, 3).reshape(B, S, 3 * S))
+
+    def dwconv_fwd(self, x, w, inv_scale, bias, y, y_pre, act, B, S, Cch):
+        xi = x.view(B, S, S, Cch).permute(0, 3, 1, 2)
+        we = w.reshape(Cch, 1, 3, 3) / (inv_scale if inv_scale is not None else 1.0)
+        z = torch.nn.functional.conv2d(xi, we, bias, padding=1, groups=Cch).permute(0, 2, 3, 1)
+        if y_pre is not None:
+            y_pre.view(B, S, S, Cch).copy_(z)
+        y.view(B, S, S, Cch).copy_(_gelu(z) if act == ACT_GELU else z)
+
+    def dwconv_bwd(self, dz, x, w, inv_scale, dx, dw, db, B, S, Cch):
+        xi = x.view(B, S, S, Cch).permute(0, 3, 1, 2).detach().clone().requires_grad_(True)
+        we = (w.reshape(Cch, 1, 3, 3) / (inv_scale if inv_scale is not None else 1.0)).detach().clone()
+        we.requires_grad_(True)
+        with torch.enable_grad():
+            z = torch.nn.functional.conv2d(xi, we, None, padding=1, groups=Cch)
+            gx, gw = torch.autograd.grad(z, (xi, we), dz.view(B, S, S, Cch).permute(0, 3, 1, 2))
+        dx.view(B, S, S, Cch).copy_(gx.permute(0, 2, 3, 1))
+        dw.view(Cch, 9).add_(gw.reshape(Cch, 9))
+        db.add_(dz.view(-1, Cch).sum(dim=0))
+
+    def add(self, a, b, out, n):
+        out.copy_(a + b)
+
+    def gelu_bwd(self, dy, z, dz, n):
+        dz.copy_(dy * _gelu_grad(z))
+
+    def colsum(self, x, out, rows, cols):
+        out.add_(x.reshape(rows, cols).sum(dim=0))
+
+    def row_scale(self, x, s, out, rows, cols):
+        out.view(rows, cols).copy_(x.reshape(rows, cols) * s[:, None])
+
+    def mean_seq_fwd(self, x, y, B, S, D):
+        y.copy_(x.view(B, S, D).mean(dim=1))
+
+    def mean_seq_bwd(self, dy, dx, B, S, D):
+        dx.copy_((dy / S)[:, None, :].expand(B, S, D))

@@ -1,0 +1,92 @@
+"""Host-side logic of the package (module tree, manual autograd formulas, stride bookkeeping,
+state-dict surface) checked on CPU by running it over tests/emulated_backend.py — a torch emulation
+of the C-ABI — against the golden fixtures of the reference.  The HIP kernels themselves are checked
+on the GPU (test_kernels_gpu.py / test_model_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+import calm_vit_dte_amd as calm
+import weights as W
+from emulated_backend import EmulatedBackend
+from helpers import CONFIGS, WEIGHT_SEED, load_golden, load_inventory, rel_err
+
+GOLDEN_CFGS = ["nano48_cls", "nano48_gen", "tiny32_cls", "tiny32_fr"]
+
+
+def build_model(name, golden, device="cpu"):
+    cfg = CONFIGS[name]
+    m = calm.ViT(torch.device(device), type=8, heads=cfg.heads, seq_length=cfg.seq_length,
+                 in_features=cfg.in_features, dim_step=cfg.dim_step, mean_var_hidden=cfg.mean_var_hidden,
+                 seq_len_step=cfg.seq_len_step, seq_len_reduce=cfg.seq_len_reduce,
+                 out_features=cfg.out_features, force_reduce=cfg.force_reduce, generate=cfg.generate)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in W.make_params(shapes, WEIGHT_SEED).items()}
+    if golden is not None:
+        for k in sd:
+            if k.endswith(("weight_u", "weight_v")):
+                sd[k] = torch.from_numpy(golden["warm/" + k].copy())
+    m.load_state_dict(sd, strict=True)
+    return m.to(device)
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+def test_state_dict_surface_matches_reference(name):
+    cfg = CONFIGS[name]
+    m = calm.ViT(torch.device("cpu"), type=8, heads=cfg.heads, seq_length=cfg.seq_length,
+                 in_features=cfg.in_features, dim_step=cfg.dim_step, mean_var_hidden=cfg.mean_var_hidden,
+                 seq_len_step=cfg.seq_len_step, seq_len_reduce=cfg.seq_len_reduce,
+                 out_features=cfg.out_features, force_reduce=cfg.force_reduce, generate=cfg.generate)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == load_inventory(name)
+    assert all(p.requires_grad for p in m.parameters())
+
+
+def test_product_path_fails_loudly_on_cpu_tensors():
+    m = build_model("tiny32_cls", None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 3, 32, 32))
+
+
+@pytest.mark.parametrize("name", GOLDEN_CFGS)
+def test_eval_forward_matches_golden(name):
+    g = load_golden(name)
+    cfg = CONFIGS[name]
+    m = build_model(name, g).eval()
+    x = torch.from_numpy(W.make_input((2, 3, cfg.seq_length, cfg.seq_length), 2))
+    with calm.backend.use_backend(EmulatedBackend()), torch.no_grad():
+        y, kl = m(x)
+    assert rel_err(y, g["eval/y"]) < 2e-5
+    assert abs(float(kl) - float(g["eval/kl"])) < 2e-5 * max(1.0, abs(float(g["eval/kl"])))
+    if name == "tiny32_cls":
+        assert isinstance(kl, float) and kl == 0.0
+
+
+@pytest.mark.parametrize("name", GOLDEN_CFGS)
+def test_train_forward_backward_matches_golden(name):
+    g = load_golden(name)
+    cfg = CONFIGS[name]
+    m = build_model(name, g).train()
+    x = torch.from_numpy(W.make_input((2, 3, cfg.seq_length, cfg.seq_length), 2)).requires_grad_(True)
+    calm.ops.set_noise_override(W.NoiseStream(7))
+    try:
+        with calm.backend.use_backend(EmulatedBackend()):
+            y, kl = m(x)
+            gy = torch.from_numpy(W.make_input(tuple(y.shape), 3, "gy"))
+            loss = (y * gy).sum() + 0.5 * kl
+            loss.backward()
+    finally:
+        calm.ops.set_noise_override(None)
+    assert rel_err(y.detach(), g["train/y"]) < 2e-5
+    assert abs(float(kl) - float(g["train/kl"])) < 2e-5 * max(1.0, abs(float(g["train/kl"])))
+    assert rel_err(x.grad, g["train/dx"]) < 1e-4
+    params = dict(m.named_parameters())
+    for n, ref in zip([str(s) for s in g["train/grad_names"]], g["train/grad_norms"]):
+        got = float(params[n].grad.norm())
+        assert abs(got - ref) <= 5e-4 * max(abs(ref), 1e-6) + 1e-9, (n, got, ref)
+    sd = m.state_dict()
+    for key in g.files:
+        if key.startswith("grad/"):
+            assert rel_err(params[key[5:]].grad, g[key]) < 1e-4, key
+        if key.startswith("post/"):
+            assert rel_err(sd[key[5:]], g[key]) < 2e-5, key

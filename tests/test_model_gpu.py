@@ -1,0 +1,172 @@
+"""Parity of the HIP path (package modules on cuda:0, through the C-ABI) against
+ (1) the golden fixtures minted from the reference (Nano-48 / Tiny-32: eval, train, backward),
+ (2) the CPU oracle on the same seeded inputs at the real head dims / stage sizes,
+ (3) size-independent properties at the bench configuration.
+north_star tolerance: 1e-3 relative fp32 (max-abs error / max-abs reference); index work bit-exact."""
+import pytest
+import torch
+
+import calm_vit_dte_amd as calm
+import weights as W
+from helpers import CONFIGS, load_golden, rel_err
+from oracle import calm_oracle as O
+from test_host_logic_cpu import build_model
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+GOLDEN_CFGS = ["nano48_cls", "nano48_gen", "tiny32_cls", "tiny32_fr"]
+
+
+@pytest.mark.parametrize("name", GOLDEN_CFGS)
+def test_eval_forward_matches_reference_golden(name):
+    g = load_golden(name)
+    cfg = CONFIGS[name]
+    m = build_model(name, g, "cuda").eval()
+    x = torch.from_numpy(W.make_input((2, 3, cfg.seq_length, cfg.seq_length), 2)).cuda()
+    with torch.no_grad():
+        y, kl = m(x)
+    assert rel_err(y, g["eval/y"]) < TOL
+    assert abs(float(kl) - float(g["eval/kl"])) < TOL * max(1.0, abs(float(g["eval/kl"])))
+
+
+@pytest.mark.parametrize("name", GOLDEN_CFGS)
+def test_train_forward_backward_matches_reference_golden(name):
+    g = load_golden(name)
+    cfg = CONFIGS[name]
+    m = build_model(name, g, "cuda").train()
+    x = torch.from_numpy(W.make_input((2, 3, cfg.seq_length, cfg.seq_length), 2)).cuda().requires_grad_(True)
+    calm.ops.set_noise_override(W.NoiseStream(7))
+    try:
+        y, kl = m(x)
+        gy = torch.from_numpy(W.make_input(tuple(y.shape), 3, "gy")).cuda()
+        loss = (y * gy).sum() + 0.5 * kl
+        loss.backward()
+    finally:
+        calm.ops.set_noise_override(None)
+    assert rel_err(y.detach(), g["train/y"]) < TOL
+    assert abs(float(kl) - float(g["train/kl"])) < TOL * max(1.0, abs(float(g["train/kl"])))
+    assert rel_err(x.grad, g["train/dx"]) < TOL
+    params = dict(m.named_parameters())
+    for n, ref in zip([str(s) for s in g["train/grad_names"]], g["train/grad_norms"]):
+        got = float(params[n].grad.norm())
+        assert abs(got - ref) <= TOL * max(abs(ref), 1e-6) + 1e-8, (n, got, ref)
+    sd = m.state_dict()
+    for key in g.files:
+        if key.startswith("grad/"):
+            assert rel_err(params[key[5:]].grad, g[key]) < TOL, key
+        if key.startswith("post/"):
+            assert rel_err(sd[key[5:]], g[key]) < TOL, key
+
+
+def _block_vs_oracle(heads, dim1, dim2, mvh, S, R, S_new, is_cross, B=2):
+    vt = calm.Vi_Tools_CNN_less_V2
+    torch.manual_seed(0)
+    blk = vt.VMLA_Block(heads=heads, dim1=dim1, dim2=dim2, mean_var_hidden=mvh, seq_length=S, seq_len_reduce=R,
+                        seq_len_new=S_new, mlp_dim=2 * dim2, force_reduce=False, is_cross=is_cross)
+    sh = O.VMLAShape(heads, dim1, dim2, mvh, S, R, S_new, False, False, is_cross)
+    shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    assert shapes == O.vmla_param_shapes("", sh, 2 * dim2)
+    P = {k: torch.from_numpy(v) for k, v in W.make_params(shapes, 77).items()}
+    xq = torch.from_numpy(W.make_input((B, S, dim1), 5, "xq"))
+    xkv = torch.from_numpy(W.make_input((B, S, dim1), 6, "xkv")) if is_cross else None
+    for i in range(3):                                   # converge u,v on the oracle side
+        with torch.no_grad():
+            O.vmla_block(P, "", sh, xq, xkv, O.LatentState(mode="sum"), True, W.NoiseStream(50 + i))
+    blk.load_state_dict({k: v.clone() for k, v in P.items()})
+    blk = blk.cuda().train()
+    for k, v in P.items():
+        if not O.is_buffer(k):
+            v.requires_grad_(True)
+    # oracle
+    xq_o = xq.clone().requires_grad_(True)
+    xkv_o = xkv.clone().requires_grad_(True) if is_cross else None
+    st = O.LatentState(mode="sum")
+    y_o = O.vmla_block(P, "", sh, xq_o, xkv_o, st, True, W.NoiseStream(9))
+    gy = torch.from_numpy(W.make_input(tuple(y_o.shape), 8, "gy"))
+    loss_o = (y_o * gy).sum() + 0.5 * st.kl_loss()
+    loss_o.backward()
+    # HIP
+    xq_h = xq.cuda().requires_grad_(True)
+    xkv_h = xkv.cuda().requires_grad_(True) if is_cross else None
+    sm = vt.ResidualStateManager(mode="sum")
+    calm.ops.set_noise_override(W.NoiseStream(9))
+    try:
+        y_h = blk(xq_h, input_kv=xkv_h, state_manager=sm, mask=True)
+        loss_h = (y_h * gy.cuda()).sum() + 0.5 * sm.get_kl_loss()
+        loss_h.backward()
+    finally:
+        calm.ops.set_noise_override(None)
+    assert rel_err(y_h.detach(), y_o.detach()) < TOL
+    assert rel_err(xq_h.grad, xq_o.grad) < TOL
+    if is_cross:
+        assert rel_err(xkv_h.grad, xkv_o.grad) < TOL
+    for n, p in blk.named_parameters():
+        assert rel_err(p.grad, P[n].grad) < TOL, n
+    for n, b in blk.state_dict().items():
+        if O.is_buffer(n):
+            assert rel_err(b, P[n]) < TOL, n
+
+
+def test_plain_block_base224_stage0_heads12_hd56():
+    _block_vs_oracle(12, 672, 672, 240, 224, 80, 224, False)
+
+
+def test_latent_cross_block_base224_672_to_528_hd44():
+    _block_vs_oracle(12, 672, 528, 240, 224, 80, 176, True)
+
+
+def test_latent_cross_block_small224_up_240_to_384_hd64():
+    _block_vs_oracle(6, 240, 384, 120, 80, 40, 128, True)
+
+
+def test_bottleneck_cross_block_hd20():
+    _block_vs_oracle(12, 240, 240, 240, 80, 80, 80, True)
+
+
+def _small224(device):
+    cfg = CONFIGS["small224_cls"]
+    m = calm.ViT(torch.device("cpu"), type=8, heads=cfg.heads, seq_length=224, in_features=672, dim_step=48,
+                 mean_var_hidden=cfg.mean_var_hidden, seq_len_step=16, seq_len_reduce=cfg.seq_len_reduce,
+                 out_features=1000, force_reduce=False, generate=False)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    params = W.make_params(shapes, 1234)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in params.items()})
+    return cfg, m.to(device), params
+
+
+def test_small224_bench_config_forward_backward_vs_oracle_and_properties():
+    cfg, m, params = _small224("cuda")
+    m.train()
+    x = torch.from_numpy(W.make_input((2, 3, 224, 224), 2)).cuda()
+    for i in range(3):                                   # warm-up power iterations (on the GPU)
+        with torch.no_grad():
+            m(x)
+    P = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for k in P:
+        if not O.is_buffer(k):
+            P[k].requires_grad_(True)
+    x1 = x[:1].clone().requires_grad_(True)
+    calm.ops.set_noise_override(W.NoiseStream(11))
+    try:
+        y, kl = m(x1)
+        gy = torch.from_numpy(W.make_input(tuple(y.shape), 3, "gy")).cuda()
+        ((y * gy).sum() + 0.5 * kl).backward()
+    finally:
+        calm.ops.set_noise_override(None)
+    assert y.shape == (1, 1000) and torch.isfinite(y).all() and float(kl) > 0
+    xo = x[:1].cpu().clone().requires_grad_(True)
+    yo, klo = O.vit_forward(P, cfg, xo, True, W.NoiseStream(11))
+    ((yo * gy.cpu()).sum() + 0.5 * klo).backward()
+    assert rel_err(y.detach(), yo.detach()) < TOL
+    assert abs(float(kl) - float(klo)) < TOL * max(1.0, abs(float(klo)))
+    assert rel_err(x1.grad, xo.grad) < TOL
+    worst = max((rel_err(p.grad, P[n].grad), n) for n, p in m.named_parameters())
+    assert worst[0] < 5 * TOL, worst
+    # properties: eval mode is deterministic and batch-composable (sample i does not see sample j)
+    m.eval()
+    with torch.no_grad():
+        ya, _ = m(x)
+        yb, _ = m(x)
+        y0, _ = m(x[:1])
+    assert torch.equal(ya, yb)
+    assert rel_err(ya[:1], y0) < 1e-5
