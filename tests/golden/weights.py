@@ -31,7 +31,7 @@ def make_tensor(name: str, shape, seed: int) -> np.ndarray:
         d = 2 * half
         base = 1.0 / (10000.0 ** (np.arange(0, d, 2, dtype=np.float64) / d))
         x = base * (1.0 + 0.05 * g.standard_normal(shape))
-    elif name.endswith((".ls_att", ".ls_mlp")) or (name.endswith(".weight") and ".ln_" in name):
+    elif name.endswith(("ls_att", "ls_mlp")) or (name.endswith(".weight") and "ln_" in name):
         x = 1.0 + 0.1 * g.standard_normal(shape)
     else:
         raise KeyError(f"no init rule for {name}")
