@@ -38,17 +38,19 @@ def _lin_fwd(be, x2, w, sigma, out, bias=None, act=ACT_NONE, col_scale=None, res
     M, K = x2.shape
     N = w.shape[0]
     be.gemm(x2, w, out, M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), inv_scale=sigma, bias=bias, act=act,
-            col_scale=col_scale, residual=residual, r=(N, 0, 0), C_pre=pre)
+            col_scale=col_scale, residual=residual, r=(N, 0, 0), C_pre=pre, split_k=1)
 
 
 def _lin_dgrad(be, dy2, w, sigma, dx, act=ACT_NONE, aux=None, residual=None, accumulate=False):
     M, N = dy2.shape
     K = w.shape[1]
     be.gemm(dy2, w, dx, M, K, N, (N, 1, 0, 0), (1, K, 0, 0), (K, 0, 0), inv_scale=sigma, act=act, aux=aux,
-            residual=residual, r=(K, 0, 0), accumulate=accumulate)
+            residual=residual, r=(K, 0, 0), accumulate=accumulate, split_k=1)
 
 
 def _lin_wgrad(be, dy2, x2, G):
+    """split_k=0: the library may slice the long token reduction and combine with fp32 atomics (the
+    only non-bitwise-reproducible launches of the path; forward and dgrad GEMMs never split)."""
     M, N = dy2.shape
     K = x2.shape[1]
     be.gemm(dy2, x2, G, N, K, M, (1, N, 0, 0), (1, K, 0, 0), (K, 0, 0))

