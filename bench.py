@@ -80,13 +80,29 @@ class GemmProfiler:
             e0.record()
             self.orig(A, B, C, M, N, K, a, b, c, batch=batch, **kw)
             e1.record()
-            self.records.append((2.0 * M * N * K * batch[0] * batch[1], e0, e1))
+            self.records.append((2.0 * M * N * K * batch[0] * batch[1], e0, e1,
+                                 (M, N, K, batch[0] * batch[1], int(a[1] == 1), int(b[1] == 1),
+                                  int(bool(kw.get("reduce_batch"))))))
         self.be.gemm = gemm
         return self
 
     def __exit__(self, *exc):
         self.be.gemm = self.orig
         return False
+
+    def report(self, path, steps):
+        """Per-shape table (M,N,K,batch,A k-contig,B k-contig,reduce): launches, ms/step, TFLOP/s."""
+        torch.cuda.synchronize()
+        agg = {}
+        for fl, e0, e1, key in self.records:
+            t = agg.setdefault(key, [0, 0.0, 0.0])
+            t[0] += 1
+            t[1] += e0.elapsed_time(e1)
+            t[2] += fl
+        with open(path, "w") as f:
+            f.write("M,N,K,batch,a_kc,b_kc,reduce,launches_per_step,ms_per_step,tflops\n")
+            for key, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(",".join(map(str, key)) + f",{n // steps},{ms / steps:.3f},{fl / (ms * 1e-3) / 1e12:.2f}\n")
 
     def summary(self):
         torch.cuda.synchronize()
@@ -140,6 +156,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--prof-steps", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gemm-report", default="", help="write a per-shape GEMM table (csv) from the profiled steps")
     args = ap.parse_args()
 
     import calm_vit_dte_amd as calm
@@ -189,6 +206,8 @@ def main():
             for _ in range(args.prof_steps):
                 step(x, y)
             flops, ms, n = prof.summary()
+            if args.gemm_report:
+                prof.report(args.gemm_report, args.prof_steps)
         achieved = flops / (ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel (calm_gemm, v_mfma_f32_32x32x2_f32)",
                     "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
