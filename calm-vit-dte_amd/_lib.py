@@ -67,6 +67,8 @@ SIGNATURES = {
     "calm_grid_transpose": (_i32, [_p, _p, _i32, _i32, _p]),
     "calm_dwconv3x3_fwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "calm_dwconv3x3_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
+    "calm_cnn_residual_fwd": (_i32, [_p] * 11 + [_i32, _i32, _i32, _p]),
+    "calm_cnn_residual_bwd": (_i32, [_p] * 18 + [_i32, _i32, _i32, _p]),
     "calm_add": (_i32, [_p, _p, _p, _i64, _p]),
     "calm_gelu_bwd": (_i32, [_p, _p, _p, _i64, _p]),
     "calm_colsum": (_i32, [_p, _p, _i64, _i32, _p]),

@@ -163,6 +163,17 @@ class HipBackend:
         _lib.check(self.lib.calm_dwconv3x3_bwd(_ptr(dz), _ptr(x), _ptr(w), _ptr(inv_scale, True), _ptr(dx),
                                                _ptr(dw), _ptr(db), B, S, Cch, _stream()), "calm_dwconv3x3_bwd")
 
+    def cnn_fwd(self, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, out, B, S, hidden):
+        _lib.check(self.lib.calm_cnn_residual_fwd(_ptr(x), _ptr(w0), _ptr(s0), _ptr(b0), _ptr(w2), _ptr(s2),
+                                                  _ptr(b2), _ptr(w4), _ptr(s4), _ptr(b4), _ptr(out), B, S, hidden,
+                                                  _stream()), "calm_cnn_residual_fwd")
+
+    def cnn_bwd(self, dy, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, dx, g0, gb0, g2, gb2, g4, gb4, B, S, hidden):
+        _lib.check(self.lib.calm_cnn_residual_bwd(_ptr(dy), _ptr(x), _ptr(w0), _ptr(s0), _ptr(b0), _ptr(w2),
+                                                  _ptr(s2), _ptr(b2), _ptr(w4), _ptr(s4), _ptr(b4), _ptr(dx),
+                                                  _ptr(g0), _ptr(gb0), _ptr(g2), _ptr(gb2), _ptr(g4), _ptr(gb4),
+                                                  B, S, hidden, _stream()), "calm_cnn_residual_bwd")
+
     # ---- helpers ----------------------------------------------------------------------
     def add(self, a, b, out, n):
         _lib.check(self.lib.calm_add(_ptr(a), _ptr(b), _ptr(out), n, _stream()), "calm_add")

@@ -492,7 +492,8 @@ class MeanSeqFn(Function):
 
 class CnnResidualFn(Function):
     """x + conv1x1(32->3)(gelu(dw3x3(gelu(conv1x1(3->32)(x))))) on the token grid as a channels-last
-    image (Vi_Tools:378-385,400-403; CALM_ViT_V2.py:60-67,80-83).  The 1x1 convs are pixel GEMMs."""
+    image (Vi_Tools:378-385,400-403; CALM_ViT_V2.py:60-67,80-83): one fused kernel each way, hidden
+    maps kept in LDS and recomputed in backward (only x is saved)."""
 
     @staticmethod
     def forward(ctx, x, w0, b0, w2, b2, w4, b4, u0, v0, s0, u2, v2, s2, u4, v4, s4):
@@ -500,50 +501,27 @@ class CnnResidualFn(Function):
         x = _c(x)
         B, S, W = x.shape
         Ch = w0.shape[0]
-        npix = B * S * S
-        dev, dt = x.device, x.dtype
-        xp = x.view(npix, 3)
-        h1p = torch.empty(npix, Ch, dtype=dt, device=dev)
-        h1 = torch.empty_like(h1p)
-        _lin_fwd(be, xp, w0.view(Ch, 3), s0, h1, bias=b0, act=ACT_GELU, pre=h1p)
-        h2p = torch.empty_like(h1p)
-        h2 = torch.empty_like(h1p)
-        be.dwconv_fwd(h1, w2, s2, b2, h2, h2p, ACT_GELU, B, S, Ch)
         out = torch.empty_like(x)
-        _lin_fwd(be, h2, w4.view(3, Ch), s4, out.view(npix, 3), bias=b4, residual=xp)
+        be.cnn_fwd(x, w0, s0, b0, w2, s2, b2, w4, s4, b4, out, B, S, Ch)
         ctx.dims = (B, S, Ch)
-        ctx.save_for_backward(xp, h1p, h1, h2p, h2, w0, w2, w4, u0, v0, s0, u2, v2, s2, u4, v4, s4)
+        ctx.save_for_backward(x, w0, b0, w2, b2, w4, b4, u0, v0, s0, u2, v2, s2, u4, v4, s4)
         return out
 
     @staticmethod
     @once_differentiable
     def backward(ctx, dy):
         be = get_backend()
-        xp, h1p, h1, h2p, h2, w0, w2, w4, u0, v0, s0, u2, v2, s2, u4, v4, s4 = ctx.saved_tensors
+        x, w0, b0, w2, b2, w4, b4, u0, v0, s0, u2, v2, s2, u4, v4, s4 = ctx.saved_tensors
         B, S, Ch = ctx.dims
-        npix = B * S * S
         dy = _c(dy)
-        dyp = dy.view(npix, 3)
-        w0m, w4m = w0.view(Ch, 3), w4.view(3, Ch)
-        G4 = torch.empty_like(w4m)
-        _lin_wgrad(be, dyp, h2, G4)
-        dW4, _ = _sn_wbwd(be, G4, w4m, u4, v4, s4)
-        db4 = _colsum(be, dyp)
-        dh2p = torch.empty_like(h2p)
-        _lin_dgrad(be, dyp, w4m, s4, dh2p, act=ACT_GELU_BWD, aux=h2p)
-        dh1 = torch.empty_like(h1)
-        G2 = torch.zeros(Ch, 9, dtype=dy.dtype, device=dy.device)
-        db2 = torch.zeros(Ch, dtype=dy.dtype, device=dy.device)
-        be.dwconv_bwd(dh2p, h1, w2, s2, dh1, G2, db2, B, S, Ch)
-        dW2, _ = _sn_wbwd(be, G2, w2.view(Ch, 9), u2, v2, s2)
-        dh1p = dh2p                                            # reuse the buffer
-        be.gelu_bwd(dh1, h1p, dh1p, dh1.numel())
-        G0 = torch.empty_like(w0m)
-        _lin_wgrad(be, dh1p, xp, G0)
-        dW0, _ = _sn_wbwd(be, G0, w0m, u0, v0, s0)
-        db0 = _colsum(be, dh1p)
+        dev, dt = dy.device, dy.dtype
         dx = torch.empty_like(dy)
-        _lin_dgrad(be, dh1p, w0m, s0, dx.view(npix, 3), residual=dyp)
+        gall = torch.zeros(Ch * 3 + Ch + Ch * 9 + Ch + 3 * Ch + 3, dtype=dt, device=dev)
+        G0, db0, G2, db2, G4, db4 = torch.split(gall, [Ch * 3, Ch, Ch * 9, Ch, 3 * Ch, 3])
+        be.cnn_bwd(dy, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, dx, G0, db0, G2, db2, G4, db4, B, S, Ch)
+        dW0, _ = _sn_wbwd(be, G0.view(Ch, 3), w0.view(Ch, 3), u0, v0, s0)
+        dW2, _ = _sn_wbwd(be, G2.view(Ch, 9), w2.view(Ch, 9), u2, v2, s2)
+        dW4, _ = _sn_wbwd(be, G4.view(3, Ch), w4.view(3, Ch), u4, v4, s4)
         return (dx, dW0.view_as(w0), db0, dW2.view_as(w2), db2, dW4.view_as(w4), db4,
                 None, None, None, None, None, None, None, None, None)
 

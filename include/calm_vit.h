@@ -191,6 +191,22 @@ int calm_dwconv3x3_bwd(const float* dz, const float* x, const float* w, const fl
                        float* dx, float* dw, float* db, int32_t B, int32_t S, int32_t C, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Fused CNN residual of Block.proj / ViT.proj (Vi_Tools:378-385,400-403; CALM_ViT_V2.py:60-67,80-83):
+ *   out = x + conv1x1_{hidden->3}(gelu(dwconv3x3(gelu(conv1x1_{3->hidden}(x)))))   on [B,S,S,3] tokens.
+ * w0:[hidden,3] w2:[hidden,9] w4:[3,hidden] are the *_orig weights, s0/s2/s4 their device sigmas.
+ * The hidden maps stay in LDS per 16x16 tile; backward recomputes them.  bwd writes dx and ACCUMULATES
+ * (atomics; caller zeroes) the gradients wrt the effective weights W/sigma (g0,g2,g4) and biases.
+ * hidden must be 32.
+ * ------------------------------------------------------------------------------------- */
+int calm_cnn_residual_fwd(const float* x, const float* w0, const float* s0, const float* b0, const float* w2,
+                          const float* s2, const float* b2, const float* w4, const float* s4, const float* b4,
+                          float* out, int32_t B, int32_t S, int32_t hidden, void* stream);
+int calm_cnn_residual_bwd(const float* dy, const float* x, const float* w0, const float* s0, const float* b0,
+                          const float* w2, const float* s2, const float* b2, const float* w4, const float* s4,
+                          const float* b4, float* dx, float* g0, float* gb0, float* g2, float* gb2, float* g4,
+                          float* gb4, int32_t B, int32_t S, int32_t hidden, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Small streaming helpers.
  * add          : out = a + b                         (residual / U-net skips, Vi_Tools:309,315,403,513-522)
  * gelu_bwd     : dz = dy * gelu'(z)                  (where it is not fused into a GEMM epilogue)

@@ -208,6 +208,31 @@ class EmulatedBackend:
         dw.view(Cch, 9).add_(gw.reshape(Cch, 9))
         db.add_(dz.view(-1, Cch).sum(dim=0))
 
+    @staticmethod
+    def _cnn(x, w0, s0, b0, w2, s2, b2, w4, s4, b4, B, S, hidden):
+        F = torch.nn.functional
+        img = x.view(B, S, S, 3).permute(0, 3, 1, 2)
+        h = _gelu(F.conv2d(img, (w0 / s0).view(hidden, 3, 1, 1), b0))
+        h = _gelu(F.conv2d(h, (w2 / s2).view(hidden, 1, 3, 3), b2, padding=1, groups=hidden))
+        h = F.conv2d(h, (w4 / s4).view(3, hidden, 1, 1), b4)
+        return (img + h).permute(0, 2, 3, 1).reshape(B, S, 3 * S)
+
+    def cnn_fwd(self, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, out, B, S, hidden):
+        out.copy_(self._cnn(x, w0, s0, b0, w2, s2, b2, w4, s4, b4, B, S, hidden))
+
+    def cnn_bwd(self, dy, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, dx, g0, gb0, g2, gb2, g4, gb4, B, S, hidden):
+        leaf = lambda t: t.detach().clone().requires_grad_(True)
+        xl = leaf(x)
+        e0, e2, e4 = leaf(w0.reshape(hidden, 3) / s0), leaf(w2.reshape(hidden, 9) / s2), leaf(w4.reshape(3, hidden) / s4)
+        c0, c2, c4 = leaf(b0), leaf(b2), leaf(b4)
+        one = torch.ones(1, device=x.device)
+        with torch.enable_grad():
+            y = self._cnn(xl, e0, one, c0, e2, one, c2, e4, one, c4, B, S, hidden)
+            gr = torch.autograd.grad(y, (xl, e0, c0, e2, c2, e4, c4), dy.reshape(B, S, 3 * S))
+        dx.copy_(gr[0].reshape(dx.shape))
+        g0.view(hidden, 3).add_(gr[1]); gb0.add_(gr[2]); g2.view(hidden, 9).add_(gr[3]); gb2.add_(gr[4])
+        g4.view(3, hidden).add_(gr[5]); gb4.add_(gr[6])
+
     def add(self, a, b, out, n):
         out.copy_(a + b)
 

@@ -310,3 +310,25 @@ def test_streaming_helpers(hip, emu):
     assert rel_err(y_hip, x.mean(dim=1)) < TOL
     hip.mean_seq_bwd(y_hip, dx_hip, 3, 48, 144)
     assert rel_err(dx_hip, (y_hip.cpu() / 48)[:, None, :].expand(3, 48, 144)) < TOL
+
+
+@pytest.mark.parametrize("B,S", [(2, 48), (1, 80), (3, 36), (2, 12), (1, 176)])
+def test_fused_cnn_residual(hip, emu, B, S):
+    """Fused conv1x1-GELU-dw3x3-GELU-conv1x1 + residual (LDS-tiled, backward recomputes) incl. ragged tiles."""
+    Ch = 32
+    x, dy = rnd(B, S, 3 * S, seed=1), rnd(B, S, 3 * S, seed=2)
+    w0, b0 = rnd(Ch, 3, seed=3) * 0.6, rnd(Ch, seed=4) * 0.1
+    w2, b2 = rnd(Ch, 9, seed=5) * 0.4, rnd(Ch, seed=6) * 0.1
+    w4, b4 = rnd(3, Ch, seed=7) * 0.3, rnd(3, seed=8) * 0.1
+    s0, s2, s4 = torch.tensor([0.9]), torch.tensor([1.2]), torch.tensor([0.7])
+    outs = []
+    for be, dev in ((emu, "cpu"), (hip, "cuda")):
+        t = [v.to(dev) for v in (x, w0, s0, b0, w2, s2, b2, w4, s4, b4)]
+        out = torch.empty(B, S, 3 * S, device=dev)
+        be.cnn_fwd(*t, out, B, S, Ch)
+        dx = torch.empty(B, S, 3 * S, device=dev)
+        gs = [torch.zeros(n, device=dev) for n in (Ch * 3, Ch, Ch * 9, Ch, 3 * Ch, 3)]
+        be.cnn_bwd(dy.to(dev), *t, dx, *gs, B, S, Ch)
+        outs.append([out, dx] + gs)
+    for a, b in zip(outs[1], outs[0]):
+        assert rel_err(a, b) < TOL
