@@ -166,8 +166,9 @@ def main():
     rank, local_rank, world = trainer.init_distributed(use_gpu=True)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = int(os.environ.get("CALM_LOCAL_DEVICE", local_rank))   # rehearsal: ranks may share a GPU
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     wl = WORKLOADS[args.workload]
     batch = args.batch or wl["batch"]
     S, classes = wl["kw"]["seq_length"], wl["kw"]["out_features"]

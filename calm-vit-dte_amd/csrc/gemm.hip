@@ -33,10 +33,11 @@ struct GemmP {
     int tiles_m, tiles_n;
 };
 
-template <bool KC, int VEC>
+template <bool KC, int VEC, int ROWS>
 __device__ __forceinline__ void load_operand(const float* __restrict__ base, long rs, long cs, int row0,
-                                             int nrows, int k0, int K, float (&reg)[8]) {
+                                             int nrows_all, int k0, int K, float (&reg)[8]) {
     const int tid = threadIdx.x;
+    const int nrows = min(nrows_all, row0 + ROWS);       // rows of THIS tile only
     if constexpr (VEC == 4) {
         if constexpr (KC) {
             const int k = k0 + 4 * (tid & 3);
@@ -110,13 +111,16 @@ __device__ __forceinline__ void store_operand(float (*T)[LDT], const float (&reg
     }
 }
 
-template <bool AKC, bool BKC, int VEC>
+template <bool AKC, bool BKC, int VEC, int BN_>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
+    constexpr int WN = BN_ == 128 ? 2 : 1;        // wave grid: 2x2 (128x128 tile) or 4x1 (128x96 tile)
+    constexpr int MT = BN_ == 128 ? 2 : 1;        // 32x32 MFMA tiles per wave along M
+    constexpr int NT = BN_ / (WN * 32);           // ... along N (2 or 3)
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     const int r = lane & 31, h = lane >> 5;
 
     // XCD-aware, bijective tile remap (blocks b and b+8 share an XCD).
@@ -127,17 +131,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
         lin = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + idx;
     }
     const int tn = lin % p.tiles_n, tm = lin / p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM, n0 = tn * BN_;
     const int z = blockIdx.y;
     const int kb_begin = z * p.kb_per_z;
     const int kb_end = min(kb_begin + p.kb_per_z, p.kb_total);
     if (kb_begin >= kb_end && p.atomic) return;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
@@ -147,8 +151,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
         const int b = kb / p.kpb;
         const int k0 = (kb - b * p.kpb) * BK;
         const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
-        load_operand<AKC, VEC>(p.A + b0 * p.a_b0 + b1 * p.a_b1, p.a_rs, p.a_cs, m0, p.M, k0, p.K, ra);
-        load_operand<BKC, VEC>(p.B + b0 * p.b_b0 + b1 * p.b_b1, p.b_rs, p.b_cs, n0, p.N, k0, p.K, rb);
+        load_operand<AKC, VEC, BM>(p.A + b0 * p.a_b0 + b1 * p.a_b1, p.a_rs, p.a_cs, m0, p.M, k0, p.K, ra);
+        load_operand<BKC, VEC, BN_>(p.B + b0 * p.b_b0 + b1 * p.b_b1, p.b_rs, p.b_cs, n0, p.N, k0, p.K, rb);
     };
 
     int buf = 0;
@@ -165,14 +169,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             const int kk = 2 * s + h;
-            const float a0 = As[buf][kk][wm * 64 + r];
-            const float a1 = As[buf][kk][wm * 64 + 32 + r];
-            const float b0 = Bs[buf][kk][wn * 64 + r];
-            const float b1 = Bs[buf][kk][wn * 64 + 32 + r];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = As[buf][kk][wm * (32 * MT) + 32 * i + r];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = Bs[buf][kk][wn * (32 * NT) + 32 * j + r];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         if (more) {
             store_operand<AKC, VEC>(As[buf ^ 1], ra);
@@ -194,16 +200,16 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
     const float* __restrict__ Rb = p.residual ? p.residual + cb0 * p.r_b0 + cb1 * p.r_b1 : nullptr;
 
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + 32 * j + r;
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn * (32 * NT) + 32 * j + r;
             if (col >= p.N) continue;
             const float bj = p.bias ? p.bias[col] : 0.f;
             const float sj = p.col_scale ? p.col_scale[col] : 1.f;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * 64 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int row = m0 + wm * (32 * MT) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (row >= p.M) continue;
                 const long off = (long)row * p.c_rs + col;
                 float v = acc[i][j][e] * scale;
@@ -225,8 +231,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
 }
 
 template <bool AKC, bool BKC, int VEC>
-int launch(const GemmP& p, dim3 grid, hipStream_t s) {
-    hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, VEC>), grid, dim3(NTHREADS), 0, s, p);
+int launch(const GemmP& p, dim3 grid, int bn, hipStream_t s) {
+    if (bn == 128) hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, VEC, 128>), grid, dim3(NTHREADS), 0, s, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<AKC, BKC, VEC, 96>), grid, dim3(NTHREADS), 0, s, p);
     CALM_LAUNCH_CHECK();
     return 0;
 }
@@ -256,8 +263,12 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     p.residual = (const float*)a->residual; p.r_rs = a->r_rs; p.r_b0 = a->r_b0; p.r_b1 = a->r_b1;
     p.C_pre = (float*)a->C_pre; p.aux = (const float*)a->aux;
     p.act = a->act; p.accumulate = a->accumulate;
+    // N tile: 128 (2x2 waves) or 96 (4x1 waves), whichever pads N less (672, 528, 1344, 1056, 480 ... are
+    // multiples of 96 or nearly so; ties go to 128 for the better A-panel reuse)
+    const int pad128 = (a->N + 127) / 128 * 128, pad96 = (a->N + 95) / 96 * 96;
+    const int bn = pad96 < pad128 ? 96 : 128;
     p.tiles_m = (a->M + BM - 1) / BM;
-    p.tiles_n = (a->N + BN - 1) / BN;
+    p.tiles_n = (a->N + bn - 1) / bn;
     const int tiles = p.tiles_m * p.tiles_n;
     const int batch = a->batch0 * a->batch1;
     p.kpb = (a->K + BK - 1) / BK;
@@ -307,13 +318,13 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     vec = vec && (bkc ? (mult4(a->K) && mult4(a->b_rs)) : (mult4(a->N) && mult4(a->b_cs)));
 
     if (vec) {
-        if (akc && bkc) return launch<true, true, 4>(p, grid, s);
-        if (akc && !bkc) return launch<true, false, 4>(p, grid, s);
-        if (!akc && bkc) return launch<false, true, 4>(p, grid, s);
-        return launch<false, false, 4>(p, grid, s);
+        if (akc && bkc) return launch<true, true, 4>(p, grid, bn, s);
+        if (akc && !bkc) return launch<true, false, 4>(p, grid, bn, s);
+        if (!akc && bkc) return launch<false, true, 4>(p, grid, bn, s);
+        return launch<false, false, 4>(p, grid, bn, s);
     }
-    if (akc && bkc) return launch<true, true, 1>(p, grid, s);
-    if (akc && !bkc) return launch<true, false, 1>(p, grid, s);
-    if (!akc && bkc) return launch<false, true, 1>(p, grid, s);
-    return launch<false, false, 1>(p, grid, s);
+    if (akc && bkc) return launch<true, true, 1>(p, grid, bn, s);
+    if (akc && !bkc) return launch<true, false, 1>(p, grid, bn, s);
+    if (!akc && bkc) return launch<false, true, 1>(p, grid, bn, s);
+    return launch<false, false, 1>(p, grid, bn, s);
 }

@@ -31,9 +31,14 @@ def init_distributed(use_gpu=True):
     local_rank = int(os.environ.get("LOCAL_RANK", rank))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not dist.is_initialized():
-        if use_gpu:
+        backend = os.environ.get("CALM_DIST_BACKEND", "nccl" if use_gpu else "gloo")
+        if use_gpu and backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        elif use_gpu:
+            # rehearsal mode: several ranks may share one GPU (CALM_LOCAL_DEVICE) and exchange through gloo
+            torch.cuda.set_device(int(os.environ.get("CALM_LOCAL_DEVICE", local_rank)))
+            dist.init_process_group(backend=backend)
         else:
             dist.init_process_group(backend="gloo")
     return rank, local_rank, world
