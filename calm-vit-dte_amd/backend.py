@@ -106,6 +106,15 @@ class HipBackend:
     def sum_heads(self, dl, dm, B, H, per_head):
         _lib.check(self.lib.calm_sum_heads(_ptr(dl), _ptr(dm), B, H, per_head, _stream()), "calm_sum_heads")
 
+    # ---- fused latent-mask attention ---------------------------------------------------
+    def attn_fwd_supported(self, Sq, Skv, H, hd):
+        return bool(self.lib.calm_attention_fwd_supported(Sq, Skv, H, hd))
+
+    def attn_fwd(self, q, k, v, w1, b1, s1, w2, b2, s2, out, R, hp, hg, Mk, P, B, Sq, Skv, H, hd):
+        _lib.check(self.lib.calm_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(w1), _ptr(b1), _ptr(s1), _ptr(w2),
+                                               _ptr(b2), _ptr(s2), _ptr(out), _ptr(R), _ptr(hp), _ptr(hg),
+                                               _ptr(Mk), _ptr(P, True), B, Sq, Skv, H, hd, _stream()), "calm_attention_fwd")
+
     # ---- latent -----------------------------------------------------------------------
     def latent_fwd(self, mv, noise, z, std, kl_sum, rows, mvh):
         _lib.check(self.lib.calm_latent_fwd(_ptr(mv), _ptr(noise, True), _ptr(z), _ptr(std), _ptr(kl_sum), rows,

@@ -1,0 +1,463 @@
+// Fused cross-axial latent-mask attention, forward (Vi_Tools_CNN_less_V2.py:288-299).
+//
+//   R      = Q_all K_all^T                      (all heads concatenated, raw, un-scaled)     [Sq,Skv]
+//   M      = W2 gelu(W1 R^T + b1) + b2          (2-layer MLP along the KEY axis, W/sigma)    [Sq,Skv]
+//   O_h    = softmax_j(Q_h K_h^T / sqrt(hd) + M) V_h                                         per head
+//
+// One workgroup = NW waves = NW 16-query tiles of one batch element; the wave keeps its 16 queries on
+// the MFMA *lane/column* index and the keys on the accumulator rows ("transposed" orientation):
+//   R^T[j,i], M^T[j,i], S^T[j,i], P^T[j,i], O^T[d,i]   with i = lane&15.
+// With v_mfma_f32_16x16x4_f32 an accumulator tile (rows in registers, column on the lane) is directly the
+// B operand of the next product that sums over its ROW index, so the whole chain
+//   R^T -> (W1 . R^T) -> gelu -> (W2 . hid) -> + scale K_h Q_h^T -> softmax -> (V_h^T . P^T)
+// runs register-to-register: nothing but the streamed operands (K/Q column chunks, W1/W2 row chunks, V
+// key chunks) goes through LDS, and the [H,Sq,Skv] probabilities never have to exist in HBM.
+// The softmax reduction over keys is 4*NJ in-lane values + two wave shuffles (xor 16, xor 32).
+// LDS images are K-major ([k][row]) with row strides chosen so that the 4 lane groups of a b32 read
+// land 16 banks apart (conflict-free); global->LDS staging is register-prefetched one chunk ahead.
+#include "common.h"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct AttnFwdP {
+    const float* q; const float* k; const float* v;
+    const float* w1; const float* b1; const float* s1;
+    const float* w2; const float* b2; const float* s2;
+    float* out;
+    float* R; float* hp; float* hg; float* Mk; float* P;   // saved for backward (P optional)
+    int B, Sq, Skv, H, hd;
+    float scale;
+};
+
+constexpr int NV_K = 2;   // float4 per thread for a [Skv x 16] chunk (needs Skv <= 32*NW)
+constexpr int NV_Q = 1;   // ... for a [16*NW x 16] query chunk
+
+// ---- staging helpers (all threads of the block cooperate) -------------------------------------
+// block of `rows` rows x 16 columns (columns c0..c0+15 of a row-major matrix, row stride `stride`),
+// staged K-MAJOR: dst[c][row].  Columns >= cmax are zero-filled.
+template <int NV> struct Regs { f32x4v v[NV]; };
+
+template <int NT, int NV>
+__device__ __forceinline__ void km_load(Regs<NV>& rg, const float* __restrict__ src, long stride, int rows, int c0,
+                                        int cmax) {
+    constexpr int nt = NT;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int f = threadIdx.x + u * nt;
+        const int row = f >> 2, c = c0 + 4 * (f & 3);
+        f32x4v val = {0.f, 0.f, 0.f, 0.f};
+        if (row < rows && c < cmax) val = *reinterpret_cast<const f32x4v*>(src + (long)row * stride + c);
+        rg.v[u] = val;
+    }
+}
+template <int NT, int NV>
+__device__ __forceinline__ void km_store(const Regs<NV>& rg, float* __restrict__ dst, int ld, int rows) {
+    constexpr int nt = NT;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int f = threadIdx.x + u * nt;
+        const int row = f >> 2, cq = 4 * (f & 3);
+        if (row < rows) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(cq + e) * ld + row] = rg.v[u][e];
+        }
+    }
+}
+// block of 16 rows x `cols` contiguous columns staged TRANSPOSED: dst[col][r] (r = 0..15), ld = row stride of dst
+template <int NT, int NV>
+__device__ __forceinline__ void tr_load(Regs<NV>& rg, const float* __restrict__ src, long stride, int cols) {
+    constexpr int nt = NT;
+    const int per_row = cols >> 2;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int f = threadIdx.x + u * nt;
+        const int r = f / per_row, cq = f - r * per_row;
+        f32x4v val = {0.f, 0.f, 0.f, 0.f};
+        if (r < 16) val = *reinterpret_cast<const f32x4v*>(src + (long)r * stride + 4 * cq);
+        rg.v[u] = val;
+    }
+}
+template <int NT, int NV>
+__device__ __forceinline__ void tr_store(const Regs<NV>& rg, float* __restrict__ dst, int ld, int cols) {
+    constexpr int nt = NT;
+    const int per_row = cols >> 2;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int f = threadIdx.x + u * nt;
+        const int r = f / per_row, cq = f - r * per_row;
+        if (r < 16) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[(4 * cq + e) * ld + r] = rg.v[u][e];
+        }
+    }
+}
+// block of 16 rows x `cols` columns staged as is: dst[r][col], zero-filled up to cols_pad
+template <int NT, int NV>
+__device__ __forceinline__ void rm_load(Regs<NV>& rg, const float* __restrict__ src, long stride, int cols, int cols_pad) {
+    constexpr int nt = NT;
+    const int per_row = cols_pad >> 2;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int f = threadIdx.x + u * nt;
+        const int r = f / per_row, cq = f - r * per_row;
+        f32x4v val = {0.f, 0.f, 0.f, 0.f};
+        if (r < 16 && 4 * cq < cols) val = *reinterpret_cast<const f32x4v*>(src + (long)r * stride + 4 * cq);
+        rg.v[u] = val;
+    }
+}
+template <int NT, int NV>
+__device__ __forceinline__ void rm_store(const Regs<NV>& rg, float* __restrict__ dst, int ld, int cols_pad) {
+    constexpr int nt = NT;
+    const int per_row = cols_pad >> 2;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int f = threadIdx.x + u * nt;
+        const int r = f / per_row, cq = f - r * per_row;
+        if (r < 16) *reinterpret_cast<f32x4v*>(dst + r * ld + 4 * cq) = rg.v[u];
+    }
+}
+
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+template <int NJ, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnFwdP p) {
+    constexpr int NTH = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int SKV = 16 * NJ;
+    constexpr int LDJ = SKV + ((SKV % 32 == 16) ? 0 : 16);    // [c][j] images: 4 lane groups 16 banks apart
+    constexpr int LDN1 = 20;                                   // W1 chunk image [j][nn]
+    constexpr int LDJ2 = SKV + 4;                              // W2 chunk image [nn][j]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int TQ = 16 * NW;
+    constexpr int LDQ = TQ + ((TQ % 32 == 16) ? 0 : 16);
+    const int r16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * TQ;                            // first query of the workgroup
+    const int nq = min(TQ, p.Sq - q0);                         // queries of this workgroup (multiple of 16)
+    const bool active = 16 * wave < nq;
+    const int iq = q0 + 16 * wave + r16;                       // this lane's query (valid if active)
+    const int D = p.H * p.hd;
+
+    const float* qb = p.q + ((long)b * p.Sq + q0) * D;
+    const float* kb = p.k + (long)b * p.Skv * D;
+    const float* vb = p.v + (long)b * p.Skv * D;
+
+    auto bufK = [&](int i) { return smem + i * 16 * LDJ; };
+    auto bufQ = [&](int i) { return smem + 32 * LDJ + i * 16 * LDQ; };
+
+    f32x4v accR[NJ];
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) accR[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+    // ================= phase 1: R^T[j,i] = sum_c K_all[j,c] Q_all[i,c] =================
+    {
+        Regs<NV_K> rk; Regs<NV_Q> rq;
+        const int nch = (D + 15) / 16;
+        km_load<NTH>(rk, kb, D, SKV, 0, D);
+        km_load<NTH>(rq, qb, D, nq, 0, D);
+        km_store<NTH>(rk, bufK(0), LDJ, SKV);
+        km_store<NTH>(rq, bufQ(0), LDQ, nq);
+        __syncthreads();
+#pragma unroll 1
+        for (int c = 0; c < nch; ++c) {
+            const int cur = c & 1;
+            if (c + 1 < nch) {
+                km_load<NTH>(rk, kb, D, SKV, 16 * (c + 1), D);
+                km_load<NTH>(rq, qb, D, nq, 16 * (c + 1), D);
+            }
+            if (active) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const float bq = bufQ(cur)[(4 * s + g) * LDQ + 16 * wave + r16];
+#pragma unroll
+                    for (int t = 0; t < NJ; ++t)
+                        accR[t] = MFMA16(bufK(cur)[(4 * s + g) * LDJ + 16 * t + r16], bq, accR[t]);
+                    __builtin_amdgcn_sched_barrier(0);       // keep at most NJ operand loads in flight
+                }
+            }
+            if (c + 1 < nch) {
+                km_store<NTH>(rk, bufK(cur ^ 1), LDJ, SKV);
+                km_store<NTH>(rq, bufQ(cur ^ 1), LDQ, nq);
+            }
+            __syncthreads();
+        }
+    }
+    if (active) {   // save R[b,i,j] (4 consecutive keys per register group)
+        float* Rrow = p.R + ((long)b * p.Sq + iq) * p.Skv;
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) *reinterpret_cast<f32x4v*>(Rrow + 16 * t + 4 * g) = accR[t];
+    }
+
+    // ================= phase 2: M^T = W2 gelu(W1 R^T + b1) + b2 =================
+    f32x4v accM[NJ];
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) accM[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    {
+        const float inv1 = 1.0f / p.s1[0], inv2 = 1.0f / p.s2[0];
+        auto bufW1 = [&](int i) { return smem + i * SKV * LDN1; };
+        auto bufW2 = [&](int i) { return smem + 2 * SKV * LDN1 + i * 16 * LDJ2; };
+        const int nch = 2 * NJ;                                 // 2*Skv hidden units, 16 per chunk
+        Regs<NV_K> r1, r2;
+        tr_load<NTH>(r1, p.w1, SKV, SKV);                            // rows n0..n0+15 of W1 [2Skv, Skv]
+        km_load<NTH>(r2, p.w2, 2 * SKV, SKV, 0, 2 * SKV);            // columns n0..n0+15 of W2 [Skv, 2Skv]
+        tr_store<NTH>(r1, bufW1(0), LDN1, SKV);
+        km_store<NTH>(r2, bufW2(0), LDJ2, SKV);
+        __syncthreads();
+#pragma unroll 1
+        for (int c = 0; c < nch; ++c) {
+            const int cur = c & 1, n0 = 16 * c;
+            if (c + 1 < nch) {
+                tr_load<NTH>(r1, p.w1 + (long)(n0 + 16) * SKV, SKV, SKV);
+                km_load<NTH>(r2, p.w2, 2 * SKV, SKV, n0 + 16, 2 * SKV);
+            }
+            if (active) {
+                // two partial accumulators: a single 16x16x4 chain would stall on its 40-cycle dependent latency
+                f32x4v hid = {0.f, 0.f, 0.f, 0.f}, hid2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int t = 0; t < NJ; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {
+                        hid = MFMA16(bufW1(cur)[(16 * t + 4 * g + r) * LDN1 + r16], accR[t][r], hid);
+                        hid2 = MFMA16(bufW1(cur)[(16 * t + 4 * g + r + 1) * LDN1 + r16], accR[t][r + 1], hid2);
+                    }
+                }
+                hid = hid + hid2;
+                const f32x4v bb = *reinterpret_cast<const f32x4v*>(p.b1 + n0 + 4 * g);
+                f32x4v pre, act;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { pre[r] = hid[r] * inv1 + bb[r]; act[r] = gelu_erf_f(pre[r]); }
+                const long ho = ((long)b * p.Sq + iq) * (2 * SKV) + n0 + 4 * g;
+                *reinterpret_cast<f32x4v*>(p.hp + ho) = pre;
+                *reinterpret_cast<f32x4v*>(p.hg + ho) = act;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int t = 0; t < NJ; ++t)
+                        accM[t] = MFMA16(bufW2(cur)[(4 * g + r) * LDJ2 + 16 * t + r16], act[r], accM[t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (c + 1 < nch) {
+                tr_store<NTH>(r1, bufW1(cur ^ 1), LDN1, SKV);
+                km_store<NTH>(r2, bufW2(cur ^ 1), LDJ2, SKV);
+            }
+            __syncthreads();
+        }
+        // the mask tile leaves the registers here (it would otherwise stay live across the head loop):
+        // Mk[b,i,j] is written once and re-read per head from L2 (NJ float4 per lane)
+        if (active) {
+            float* Mrow = p.Mk + ((long)b * p.Sq + iq) * p.Skv;
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) {
+                const f32x4v bb = *reinterpret_cast<const f32x4v*>(p.b2 + 16 * t + 4 * g);
+                f32x4v m;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m[r] = accM[t][r] * inv2 + bb[r];
+                *reinterpret_cast<f32x4v*>(Mrow + 16 * t + 4 * g) = m;
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+
+    // ================= phase 3: per head  softmax(scale K_h Q_h^T + M^T) , O^T = V_h^T P^T =================
+    const int hd = p.hd;
+    const int DT = (hd + 15) / 16;                              // output d-tiles (<= 8)
+    const int hdp = 16 * DT;
+    const int LDV = hdp + 4;                                    // 4*LDV % 32 == 16
+    float* bufV = smem + 32 * LDJ + 32 * LDQ;                   // the WHOLE V_h [Skv][LDV], filled during the QK loop
+    const int v_per_row = hdp >> 2;                             // float4 per V row
+    const int v_total = SKV * v_per_row;
+    const int nchq = (hd + 15) / 16;                            // QK^T column chunks
+    const int v_share = (v_total + nchq - 1) / nchq;            // float4 of V staged per QK chunk (<= NV_K * NTH)
+#pragma unroll 1
+    for (int h = 0; h < p.H; ++h) {
+        const float* qh = qb + h * hd;
+        const float* kh = kb + h * hd;
+        const float* vh = vb + h * hd;
+        f32x4v accS[NJ];
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) accS[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        {
+            Regs<NV_K> rk; Regs<NV_Q> rq; Regs<NV_K> rv;
+            auto v_load = [&](int c) {
+#pragma unroll
+                for (int u = 0; u < NV_K; ++u) {
+                    const int f = c * v_share + tid + u * NTH;
+                    const int row = f / v_per_row, cq = f - row * v_per_row;
+                    f32x4v val = {0.f, 0.f, 0.f, 0.f};
+                    if (tid + u * NTH < v_share && f < v_total && 4 * cq < hd)
+                        val = *reinterpret_cast<const f32x4v*>(vh + (long)row * D + 4 * cq);
+                    rv.v[u] = val;
+                }
+            };
+            auto v_store = [&](int c) {
+#pragma unroll
+                for (int u = 0; u < NV_K; ++u) {
+                    const int f = c * v_share + tid + u * NTH;
+                    const int row = f / v_per_row, cq = f - row * v_per_row;
+                    if (tid + u * NTH < v_share && f < v_total)
+                        *reinterpret_cast<f32x4v*>(bufV + row * LDV + 4 * cq) = rv.v[u];
+                }
+            };
+            km_load<NTH>(rk, kh, D, SKV, 0, hd);
+            km_load<NTH>(rq, qh, D, nq, 0, hd);
+            km_store<NTH>(rk, bufK(0), LDJ, SKV);
+            km_store<NTH>(rq, bufQ(0), LDQ, nq);
+            __syncthreads();
+#pragma unroll 1
+            for (int c = 0; c < nchq; ++c) {
+                const int cur = c & 1;
+                v_load(c);
+                if (c + 1 < nchq) {
+                    km_load<NTH>(rk, kh, D, SKV, 16 * (c + 1), hd);
+                    km_load<NTH>(rq, qh, D, nq, 16 * (c + 1), hd);
+                }
+                if (active) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const float bq = bufQ(cur)[(4 * s + g) * LDQ + 16 * wave + r16];
+#pragma unroll
+                        for (int t = 0; t < NJ; ++t)
+                            accS[t] = MFMA16(bufK(cur)[(4 * s + g) * LDJ + 16 * t + r16], bq, accS[t]);
+                    }
+                }
+                v_store(c);
+                if (c + 1 < nchq) {
+                    km_store<NTH>(rk, bufK(cur ^ 1), LDJ, SKV);
+                    km_store<NTH>(rq, bufQ(cur ^ 1), LDQ, nq);
+                }
+                __syncthreads();
+            }
+        }
+        // softmax over the keys: 4*NJ in-lane values, then the 4 lane groups (xor 16, xor 32)
+        float mx = -INFINITY;
+        {
+            // own writes of this thread; the pointer is laundered so that the compiler re-loads the tile per
+            // head instead of forwarding the stored values (which would keep 4*NJ registers live)
+            const float* Mrow = p.Mk + ((long)b * p.Sq + (active ? iq : q0)) * p.Skv;
+            asm volatile("" : "+v"(Mrow));
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) {
+                const f32x4v m = *reinterpret_cast<const f32x4v*>(Mrow + 16 * t + 4 * g);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    accS[t][r] = accS[t][r] * p.scale + m[r];
+                    mx = fmaxf(mx, accS[t][r]);
+                }
+            }
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < NJ; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                accS[t][r] = expf(accS[t][r] - mx);
+                sum += accS[t][r];
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) accS[t] = accS[t] * inv;
+        if (active && p.P) {
+            float* Prow = p.P + (((long)b * p.H + h) * p.Sq + iq) * p.Skv;
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) *reinterpret_cast<f32x4v*>(Prow + 16 * t + 4 * g) = accS[t];
+        }
+        // O^T[d,i] = sum_j V_h[j,d] P^T[j,i]   (V_h complete in LDS since the last barrier of the QK loop)
+        if (active) {
+            float* orow = p.out + ((long)b * p.Sq + iq) * D + h * hd;
+#pragma unroll 1
+            for (int d = 0; d < DT; d += 2) {                   // two d-tiles = two independent MFMA chains
+                f32x4v accO = {0.f, 0.f, 0.f, 0.f}, accO2 = {0.f, 0.f, 0.f, 0.f};
+                const float* vcol = bufV + 16 * d + r16;
+                const int d2 = (d + 1 < DT) ? 16 : 0;           // odd DT: the second chain redoes tile d (discarded)
+#pragma unroll
+                for (int t = 0; t < NJ; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        accO = MFMA16(vcol[(16 * t + 4 * g + r) * LDV], accS[t][r], accO);
+                        accO2 = MFMA16(vcol[(16 * t + 4 * g + r) * LDV + d2], accS[t][r], accO2);
+                    }
+                if (16 * d + 4 * g < hd) *reinterpret_cast<f32x4v*>(orow + 16 * d + 4 * g) = accO;
+                if (d + 1 < DT && 16 * (d + 1) + 4 * g < hd)
+                    *reinterpret_cast<f32x4v*>(orow + 16 * (d + 1) + 4 * g) = accO2;
+            }
+        }
+        __syncthreads();                                        // bufV / bufK / bufQ are rewritten by the next head
+    }
+}
+
+inline int pick_waves(int tiles) {
+    const int groups = (tiles + 7) / 8;
+    return (tiles + groups - 1) / groups;
+}
+
+template <int NJ, int NW>
+int launch_fwd(const AttnFwdP& p, hipStream_t s) {
+    const int tiles = p.Sq / 16;
+    const int TQ = 16 * NW;
+    const int SKV = 16 * NJ;
+    const int LDJ = SKV + ((SKV % 32 == 16) ? 0 : 16);
+    const int LDQ = TQ + ((TQ % 32 == 16) ? 0 : 16);
+    const int hdp = (p.hd + 15) / 16 * 16;
+    const int LDV = hdp + 4;
+    const int ph13 = 32 * LDJ + 32 * LDQ + SKV * LDV;       // K/Q chunk double buffers + the whole V_h
+    const int ph2 = 2 * SKV * 20 + 32 * (SKV + 4);
+    const size_t lds = sizeof(float) * (size_t)(ph13 > ph2 ? ph13 : ph2);
+    if (lds > 160 * 1024) return CALM_E_UNSUPP;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<NJ, NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((tiles + NW - 1) / NW, p.B);
+    hipLaunchKernelGGL((attn_fwd_kernel<NJ, NW>), grid, dim3(64 * NW), lds, s, p);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int calm_attention_fwd_supported(int32_t Sq, int32_t Skv, int32_t H, int32_t hd) {
+    if (Sq <= 0 || Skv <= 0 || H <= 0 || hd <= 0) return 0;
+    if (Sq != Skv || (Sq & 15) || (hd & 3) || hd > 128) return 0;   // every attention of the model has Sq == Skv
+    const int nj = Skv / 16;
+    if (!(nj == 2 || nj == 3 || nj == 5 || nj == 8 || nj == 11 || nj == 14)) return 0;
+    // staging registers: a [Skv x 16] chunk is 4*Skv float4 (NV_K per thread), a [16 x hd_pad] V chunk 4*hd_pad
+    const int nt = 64 * pick_waves(Sq / 16);
+    if (4 * Skv > NV_K * nt) return 0;
+    const int hdp = (hd + 15) / 16 * 16, ldj = Skv + ((Skv % 32 == 16) ? 0 : 16), tq = nt / 4;
+    const int ldq = tq + ((tq % 32 == 16) ? 0 : 16);
+    if ((32 * ldj + 32 * ldq + Skv * (hdp + 4)) * 4 > 160 * 1024) return 0;   // whole V_h must fit in LDS
+    return 1;
+}
+
+int calm_attention_fwd(const float* q, const float* k, const float* v, const float* w1, const float* b1,
+                       const float* s1, const float* w2, const float* b2, const float* s2, float* out, float* R,
+                       float* hp, float* hg, float* Mk, float* P, int32_t B, int32_t Sq, int32_t Skv, int32_t H, int32_t hd,
+                       void* stream) {
+    if (!q || !k || !v || !w1 || !b1 || !s1 || !w2 || !b2 || !s2 || !out || !R || !hp || !hg || !Mk || B <= 0)
+        return CALM_E_INVAL;
+    if (!calm_attention_fwd_supported(Sq, Skv, H, hd)) return CALM_E_UNSUPP;
+    if (B > 65535) return CALM_E_UNSUPP;
+    AttnFwdP p{q, k, v, w1, b1, s1, w2, b2, s2, out, R, hp, hg, Mk, P, B, Sq, Skv, H, hd, 1.0f / sqrtf((float)hd)};
+    hipStream_t s = as_stream(stream);
+    switch (Skv / 16) {
+        // <key tiles, waves per workgroup = pick_waves(Sq/16)>
+        case 2: return launch_fwd<2, 2>(p, s);
+        case 3: return launch_fwd<3, 3>(p, s);
+        case 5: return launch_fwd<5, 5>(p, s);
+        case 8: return launch_fwd<8, 8>(p, s);
+        case 11: return launch_fwd<11, 6>(p, s);
+        case 14: return launch_fwd<14, 7>(p, s);
+    }
+    return CALM_E_UNSUPP;
+}
+
+}  // extern "C"

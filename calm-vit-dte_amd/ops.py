@@ -293,25 +293,28 @@ class LatentMaskAttentionFn(Function):
         Skv = k.shape[1]
         hd = D // H
         dev, dt = q.device, q.dtype
-        # raw all-head logits R = Q_all K_all^T
         R = torch.empty(B, Sq, Skv, dtype=dt, device=dev)
-        be.gemm(q, k, R, Sq, Skv, D, (D, 1, Sq * D, 0), (D, 1, Skv * D, 0), (Skv, Sq * Skv, 0), batch=(B, 1))
-        # mask MLP along the key axis
-        R2 = R.view(B * Sq, Skv)
         hp = torch.empty(B * Sq, w1.shape[0], dtype=dt, device=dev)
         hg = torch.empty_like(hp)
-        _lin_fwd(be, R2, w1, s1, hg, bias=b1, act=ACT_GELU, pre=hp)
-        Mk = torch.empty(B * Sq, Skv, dtype=dt, device=dev)
-        _lin_fwd(be, hg, w2, s2, Mk, bias=b2)
-        # per-head logits + mask, softmax, PV
         P = torch.empty(B, H, Sq, Skv, dtype=dt, device=dev)
-        scale = 1.0 / math.sqrt(hd)
-        be.gemm(q, k, P, Sq, Skv, hd, (D, 1, Sq * D, hd), (D, 1, Skv * D, hd), (Skv, H * Sq * Skv, Sq * Skv),
-                batch=(B, H), alpha=scale, residual=Mk, r=(Skv, Sq * Skv, 0))
-        be.softmax_fwd(P, B * H * Sq, Skv)
         out = torch.empty(B, Sq, D, dtype=dt, device=dev)
-        be.gemm(P, v, out, Sq, hd, Skv, (Skv, 1, H * Sq * Skv, Sq * Skv), (1, D, Skv * D, hd), (D, Sq * D, hd),
-                batch=(B, H))
+        if be.attn_fwd_supported(Sq, Skv, H, hd):
+            # one fused kernel: mask produced and applied in-kernel, softmax by wave shuffles
+            Mk = torch.empty(B * Sq, Skv, dtype=dt, device=dev)
+            be.attn_fwd(q, k, v, w1, b1, s1, w2, b2, s2, out, R, hp, hg, Mk, P, B, Sq, Skv, H, hd)
+        else:
+            # shapes without a fused instantiation: the same arithmetic composed from GEMM + softmax kernels
+            be.gemm(q, k, R, Sq, Skv, D, (D, 1, Sq * D, 0), (D, 1, Skv * D, 0), (Skv, Sq * Skv, 0), batch=(B, 1))
+            R2 = R.view(B * Sq, Skv)
+            _lin_fwd(be, R2, w1, s1, hg, bias=b1, act=ACT_GELU, pre=hp)
+            Mk = torch.empty(B * Sq, Skv, dtype=dt, device=dev)
+            _lin_fwd(be, hg, w2, s2, Mk, bias=b2)
+            scale = 1.0 / math.sqrt(hd)
+            be.gemm(q, k, P, Sq, Skv, hd, (D, 1, Sq * D, hd), (D, 1, Skv * D, hd), (Skv, H * Sq * Skv, Sq * Skv),
+                    batch=(B, H), alpha=scale, residual=Mk, r=(Skv, Sq * Skv, 0))
+            be.softmax_fwd(P, B * H * Sq, Skv)
+            be.gemm(P, v, out, Sq, hd, Skv, (Skv, 1, H * Sq * Skv, Sq * Skv), (1, D, Skv * D, hd), (D, Sq * D, hd),
+                    batch=(B, H))
         ctx.H = H
         ctx.save_for_backward(q, k, v, R, hp, hg, P, w1, w2, u1, v1, s1, u2, v2, s2)
         return out

@@ -120,6 +120,23 @@ int calm_softmax_bwd(const float* p, float* dp, int64_t rows, int32_t cols, void
 int calm_sum_heads(const float* dl, float* dm, int32_t B, int32_t H, int64_t per_head, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Fused cross-axial latent-mask attention, forward (Vi_Tools:288-299):
+ *   R = Q_all K_all^T;  M = W2 gelu(W1 R^T + b1) + b2 (along the key axis, weights divided by their
+ *   sigmas);  out_h = softmax(Q_h K_h^T / sqrt(hd) + M) V_h  — the mask is produced and applied in-kernel.
+ * q:[B,Sq,H*hd]  k,v:[B,Skv,H*hd]  w1:[2Skv,Skv] b1:[2Skv]  w2:[Skv,2Skv] b2:[Skv]  out:[B,Sq,H*hd].
+ * Saved for backward: R:[B,Sq,Skv], hp/hg:[B,Sq,2Skv] (mask-MLP hidden before/after GELU), the mask
+ * Mk:[B,Sq,Skv] and, if P != NULL, the probabilities P:[B,H,Sq,Skv].
+ * calm_attention_fwd_supported() tells whether the shape has a fused instantiation
+ * (Sq,Skv multiples of 16 with Skv/16 in {2,3,5,8,11,14}, hd%4==0, hd<=128); otherwise the caller
+ * composes the same result from calm_gemm + calm_softmax_fwd.
+ * ------------------------------------------------------------------------------------- */
+int calm_attention_fwd_supported(int32_t Sq, int32_t Skv, int32_t H, int32_t hd);
+int calm_attention_fwd(const float* q, const float* k, const float* v, const float* w1, const float* b1,
+                       const float* s1, const float* w2, const float* b2, const float* s2, float* out, float* R,
+                       float* hp, float* hg, float* Mk, float* P, int32_t B, int32_t Sq, int32_t Skv, int32_t H, int32_t hd,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Latent bottleneck sampling (Vi_Tools:232-242) + KL partial sum (Vi_Tools:24-25).
  * mv: [rows, 2*mvh] (mean | raw).  std = softplus(raw)+1e-6;  z = mean + noise*std (noise NULL
  * in eval: z = mean).  kl_sum (device scalar, caller zeroes) += sum(1 + 2 log std - mean^2 - std^2).

@@ -133,6 +133,27 @@ class EmulatedBackend:
     def sum_heads(self, dl, dm, B, H, per_head):
         dm.view(B, per_head).copy_(dl.view(B, H, per_head).sum(dim=1))
 
+    def attn_fwd_supported(self, Sq, Skv, H, hd):
+        nj = Skv // 16
+        return Sq == Skv and Sq % 16 == 0 and hd % 4 == 0 and hd <= 128 and nj in (2, 3, 5, 8, 11, 14)
+
+    def attn_fwd(self, q, k, v, w1, b1, s1, w2, b2, s2, out, R, hp, hg, Mk, P, B, Sq, Skv, H, hd):
+        D = H * hd
+        q3, k3, v3 = q.view(B, Sq, D), k.view(B, Skv, D), v.view(B, Skv, D)
+        raw = q3 @ k3.transpose(1, 2)
+        pre = raw @ (w1 / s1).t() + b1
+        act = _gelu(pre)
+        mask = act @ (w2 / s2).t() + b2
+        qh, kh, vh = (t.view(B, -1, H, hd).transpose(1, 2) for t in (q3, k3, v3))
+        prob = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(hd) + mask[:, None], dim=-1)
+        out.view(B, Sq, D).copy_((prob @ vh).transpose(1, 2).reshape(B, Sq, D))
+        R.view(B, Sq, Skv).copy_(raw)
+        hp.view(B, Sq, 2 * Skv).copy_(pre)
+        hg.view(B, Sq, 2 * Skv).copy_(act)
+        Mk.view(B, Sq, Skv).copy_(mask)
+        if P is not None:
+            P.view(B, H, Sq, Skv).copy_(prob)
+
     def latent_fwd(self, mv, noise, z, std, kl_sum, rows, mvh):
         m2 = mv.reshape(rows, 2 * mvh)
         mean, raw = m2[:, :mvh], m2[:, mvh:]
