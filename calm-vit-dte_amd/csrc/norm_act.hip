@@ -81,6 +81,118 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ dy
     }
 }
 
+// Vectorised variants: the whole row lives in registers as NV float4 per lane (D <= 256*NV, D % 4 == 0),
+// one HBM pass per tensor, 16-byte coalesced accesses.
+template <int NV>
+__global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ y, float* __restrict__ mean,
+                                                        float* __restrict__ rstd, long rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (NT / 64);
+    const int nv4 = D >> 2;
+    f32x4 wv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c4 = lane + 64 * i;
+        wv[i] = c4 < nv4 ? reinterpret_cast<const f32x4*>(w)[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (long row = wave; row < rows; row += nwaves) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
+        f32x4 xv[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c4 = lane + 64 * i;
+            xv[i] = c4 < nv4 ? xr[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s += xv[i][0] + xv[i][1] + xv[i][2] + xv[i][3];
+        }
+        const float mu = wave_sum(s) / D;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (lane + 64 * i < nv4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float d = xv[i][e] - mu; q += d * d; }
+            }
+        }
+        const float rs = rsqrtf(wave_sum(q) / D + eps);
+        f32x4* yr = reinterpret_cast<f32x4*>(y + row * D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nv4) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (xv[i][e] - mu) * rs * wv[i][e];
+                yr[c4] = o;
+            }
+        }
+        if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    }
+}
+
+template <int NV>
+__global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ w, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, float* __restrict__ dx,
+                                                        float* __restrict__ dw, long rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (NT / 64);
+    const int nv4 = D >> 2;
+    f32x4 wv[NV], dwacc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c4 = lane + 64 * i;
+        wv[i] = c4 < nv4 ? reinterpret_cast<const f32x4*>(w)[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        dwacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    for (long row = wave; row < rows; row += nwaves) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
+        const f32x4* gr = reinterpret_cast<const f32x4*>(dy + row * D);
+        const float mu = mean[row], rs = rstd[row];
+        f32x4 xh[NV], gv[NV];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c4 = lane + 64 * i;
+            const bool in = c4 < nv4;
+            const f32x4 xv = in ? xr[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            gv[i] = in ? gr[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xh[i][e] = in ? (xv[e] - mu) * rs : 0.f;
+                const float g = gv[i][e] * wv[i][e];
+                c1 += g; c2 += g * xh[i][e];
+            }
+        }
+        c1 = wave_sum(c1) / D; c2 = wave_sum(c2) / D;
+        f32x4* dr = reinterpret_cast<f32x4*>(dx + row * D);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c4 = lane + 64 * i;
+            if (c4 < nv4) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = rs * (gv[i][e] * wv[i][e] - c1 - xh[i][e] * c2);
+                    dwacc[i][e] += gv[i][e] * xh[i][e];
+                }
+                dr[c4] = o;
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c4 = lane + 64 * i;
+        if (c4 < nv4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(dw + 4 * c4 + e, dwacc[i][e]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ RoPE
 __global__ void rope_table_kernel(const float* __restrict__ inv_freq, float* __restrict__ table, int S, int half) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -347,6 +459,20 @@ extern "C" {
 int calm_layernorm_fwd(const float* x, const float* w, float* y, float* mean, float* rstd, int64_t rows, int32_t D,
                        float eps, void* stream) {
     if (!x || !w || !y || !mean || !rstd || rows <= 0 || D <= 0) return CALM_E_INVAL;
+    if ((D & 3) == 0 && D <= 256 * 5 && aligned16(x) && aligned16(y) && aligned16(w)) {
+        const dim3 g(grid_for(rows, NT / 64)), b(NT);
+        hipStream_t s = as_stream(stream);
+        const int nv = (D / 4 + 63) / 64;
+        switch (nv) {
+            case 1: hipLaunchKernelGGL(ln_fwd_vec_kernel<1>, g, b, 0, s, x, w, y, mean, rstd, (long)rows, D, eps); break;
+            case 2: hipLaunchKernelGGL(ln_fwd_vec_kernel<2>, g, b, 0, s, x, w, y, mean, rstd, (long)rows, D, eps); break;
+            case 3: hipLaunchKernelGGL(ln_fwd_vec_kernel<3>, g, b, 0, s, x, w, y, mean, rstd, (long)rows, D, eps); break;
+            case 4: hipLaunchKernelGGL(ln_fwd_vec_kernel<4>, g, b, 0, s, x, w, y, mean, rstd, (long)rows, D, eps); break;
+            default: hipLaunchKernelGGL(ln_fwd_vec_kernel<5>, g, b, 0, s, x, w, y, mean, rstd, (long)rows, D, eps); break;
+        }
+        CALM_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for(rows, NT / 64)), dim3(NT), 0, as_stream(stream), x, w, y, mean,
                        rstd, (long)rows, D, eps);
     CALM_LAUNCH_CHECK();
@@ -359,6 +485,20 @@ int calm_layernorm_bwd(const float* dy, const float* x, const float* w, const fl
     if (D > 64 * LN_MAXC) return CALM_E_UNSUPP;
     int g = grid_for(rows, NT / 64);
     if (g > 1024) g = 1024;
+    if ((D & 3) == 0 && D <= 256 * 5 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(w)) {
+        const dim3 gd(g), b(NT);
+        hipStream_t s = as_stream(stream);
+        const int nv = (D / 4 + 63) / 64;
+        switch (nv) {
+            case 1: hipLaunchKernelGGL(ln_bwd_vec_kernel<1>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, (long)rows, D); break;
+            case 2: hipLaunchKernelGGL(ln_bwd_vec_kernel<2>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, (long)rows, D); break;
+            case 3: hipLaunchKernelGGL(ln_bwd_vec_kernel<3>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, (long)rows, D); break;
+            case 4: hipLaunchKernelGGL(ln_bwd_vec_kernel<4>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, (long)rows, D); break;
+            default: hipLaunchKernelGGL(ln_bwd_vec_kernel<5>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, (long)rows, D); break;
+        }
+        CALM_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(g), dim3(NT), 0, as_stream(stream), dy, x, w, mean, rstd, dx, dw,
                        (long)rows, D);
     CALM_LAUNCH_CHECK();

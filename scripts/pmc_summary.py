@@ -16,7 +16,8 @@ for d in dirs:
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         seen = set()
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0][:80]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            k = k.split("(")[0][:80]
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             key = (f, r["Dispatch_Id"])
             if key not in seen and r["Counter_Name"] in ("GRBM_GUI_ACTIVE", "FETCH_SIZE", "WRITE_SIZE"):

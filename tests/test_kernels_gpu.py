@@ -138,7 +138,8 @@ def test_gemm_rejects_bad_arguments(hip):
         hip.gemm(A.cpu(), A, A, 8, 8, 8, (8, 1, 0, 0), (8, 1, 0, 0), (8, 0, 0))  # CPU tensor
 
 
-@pytest.mark.parametrize("rows,D", [(37, 144), (1000, 672), (5, 36), (64, 1152)])
+@pytest.mark.parametrize("rows,D", [(37, 144), (1000, 672), (5, 36), (64, 1152), (2500, 528), (300, 240),
+                                    (33, 30), (9, 1302)])      # last two: scalar (D%4 != 0 / D > 1280) kernels
 def test_layernorm(hip, emu, rows, D):
     x, w, dy = rnd(rows, D, seed=1) * 2 + 0.5, 1 + 0.1 * rnd(D, seed=2), rnd(rows, D, seed=3)
     outs = []
