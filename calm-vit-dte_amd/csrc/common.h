@@ -15,13 +15,28 @@
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// erf-GELU with ONE exponential: erf by Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, the level of
+// fp32 erff itself), and the same e^{-x^2/2} serves the Gaussian term of the derivative.
+//   gelu(x)  = 0.5 x (1 + erf(x/sqrt2)),   gelu'(x) = 0.5 (1 + erf(x/sqrt2)) + x e^{-x^2/2} / sqrt(2 pi)
+__device__ __forceinline__ void gelu_parts_f(float x, float& cdf, float& gauss) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float e = __expf(-z * z);                       // e^{-x^2/2}
+    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f),
+                                        -0.284496736f), 0.254829592f);
+    const float erf_abs = fmaf(-poly, e, 1.0f);           // erf(|x|/sqrt2)
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    gauss = e;
+}
 __device__ __forceinline__ float gelu_erf_f(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    float cdf, g;
+    gelu_parts_f(x, cdf, g);
+    return x * cdf;
 }
 __device__ __forceinline__ float gelu_erf_grad_f(float x) {
-    // d/dx [0.5 x (1 + erf(x/sqrt2))] = 0.5 (1 + erf(x/sqrt2)) + x * exp(-x^2/2) / sqrt(2 pi)
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) +
-           x * 0.39894228040143267794f * expf(-0.5f * x * x);
+    float cdf, g;
+    gelu_parts_f(x, cdf, g);
+    return fmaf(x * 0.39894228040143267794f, g, cdf);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

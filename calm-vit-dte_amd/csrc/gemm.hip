@@ -279,13 +279,13 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     if (a->reduce_batch) {
         p.atomic = 1;
         p.kb_total = batch * p.kpb;
-        nsplit = a->split_k > 1 ? a->split_k : (1024 + tiles - 1) / tiles;
+        nsplit = a->split_k > 1 ? a->split_k : 768 / tiles   /* one resident round: 256 CUs x 3 workgroups */;
         const int max_split = (p.kb_total + 7) / 8;
         if (nsplit > max_split) nsplit = max_split;
         if (nsplit < 1) nsplit = 1;
     } else if (a->split_k > 1 || (a->split_k == 0 && batch == 1 && trivial_epi && tiles < 256 && p.kpb >= 64)) {
         if (batch != 1) return CALM_E_UNSUPP;
-        nsplit = a->split_k > 1 ? a->split_k : (768 + tiles - 1) / tiles;
+        nsplit = a->split_k > 1 ? a->split_k : 768 / tiles;
         const int max_split = (p.kpb + 15) / 16;
         if (nsplit > max_split) nsplit = max_split;
         if (nsplit < 1) nsplit = 1;

@@ -74,10 +74,16 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ dy
             }
         }
     }
+    __shared__ float red[(NT / 64) * 64 * LN_MAXC];
+    const int wv_id = threadIdx.x >> 6;
 #pragma unroll
-    for (int i = 0; i < LN_MAXC; ++i) {
-        const int c = lane + 64 * i;
-        if (c < D) atomicAdd(dw + c, dwacc[i]);
+    for (int i = 0; i < LN_MAXC; ++i) red[wv_id * (64 * LN_MAXC) + lane + 64 * i] = dwacc[i];
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += NT) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT / 64; ++k) s += red[k * (64 * LN_MAXC) + c];
+        atomicAdd(dw + c, s);
     }
 }
 
@@ -183,13 +189,22 @@ __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const float* __restrict_
             }
         }
     }
+    // block-level reduction of dw over the 4 waves, then ONE atomic per column per block (per-wave atomics
+    // on the same D addresses from thousands of waves cost a ~400 us floor per call)
+    __shared__ float red[(NT / 64) * 256 * NV * 4];
+    const int wv_id = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c4 = lane + 64 * i;
-        if (c4 < nv4) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(dw + 4 * c4 + e, dwacc[i][e]);
-        }
+        for (int e = 0; e < 4; ++e) red[wv_id * (256 * NV) + 4 * c4 + e] = dwacc[i][e];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += NT) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NT / 64; ++k) s += red[k * (256 * NV) + c];
+        atomicAdd(dw + c, s);
     }
 }
 
@@ -484,7 +499,7 @@ int calm_layernorm_bwd(const float* dy, const float* x, const float* w, const fl
     if (!dy || !x || !w || !mean || !rstd || !dx || !dw || rows <= 0 || D <= 0) return CALM_E_INVAL;
     if (D > 64 * LN_MAXC) return CALM_E_UNSUPP;
     int g = grid_for(rows, NT / 64);
-    if (g > 1024) g = 1024;
+    if (g > 512) g = 512;
     if ((D & 3) == 0 && D <= 256 * 5 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(w)) {
         const dim3 gd(g), b(NT);
         hipStream_t s = as_stream(stream);
