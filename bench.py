@@ -42,6 +42,15 @@ WORKLOADS = {
                            seq_len_step=4, seq_len_reduce=16, out_features=10), gflop_img=0.500, batch=64),
 }
 PEAK_FP32_MATRIX_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+PEAK_BF16_DENSE_TFLOPS = 2500.0
+# per precision: (dtype label, matrix-pipe peak for the ALGORITHMIC flops, kernel label)
+PRECISION_INFO = {
+    "fp32": ("f32", PEAK_FP32_MATRIX_TFLOPS, "gemm_f32_kernel (calm_gemm, v_mfma_f32_32x32x2_f32)"),
+    "bf16": ("bf16 operands / f32 accumulate (f32 tensors)", PEAK_BF16_DENSE_TFLOPS,
+             "gemm_bf16c_kernel<1> (calm_gemm, v_mfma_f32_32x32x16_bf16)"),
+    "bf16x3": ("f32 via bf16x3 split", PEAK_BF16_DENSE_TFLOPS / 3.0,
+               "gemm_bf16c_kernel<3> (calm_gemm, 3 x v_mfma_f32_32x32x16_bf16 per product)"),
+}
 WEIGHT_SEED = 1234
 
 
@@ -154,6 +163,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="small224", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
+                    help="matrix pipe of the GEMMs (tensors stay fp32): exact fp32 MFMA (default, config #2), "
+                         "bf16 operands (autocast arithmetic, configs #3-5), or the fp32-accurate bf16x3 split")
     ap.add_argument("--prof-steps", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-report", default="", help="write a per-shape GEMM table (csv) from the profiled steps")
@@ -173,6 +185,7 @@ def main():
     batch = args.batch or wl["batch"]
     S, classes = wl["kw"]["seq_length"], wl["kw"]["out_features"]
 
+    calm.backend.set_matmul_precision(args.precision)
     model = build_model(calm, wl["kw"], device).train()
     trainer.sync_module_states(model)
     opt = trainer.make_optimizer(model)
@@ -210,9 +223,10 @@ def main():
             if args.gemm_report:
                 prof.report(args.gemm_report, args.prof_steps)
         achieved = flops / (ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "gemm_f32_kernel (calm_gemm, v_mfma_f32_32x32x2_f32)",
-                    "achieved": round(achieved, 2), "peak": PEAK_FP32_MATRIX_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_FP32_MATRIX_TFLOPS, 4), "traffic": None,
+        _, peak, klabel = PRECISION_INFO[args.precision]
+        roofline = {"bound": "mfma", "kernel": klabel,
+                    "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": None,
                     "launches_per_step": n // args.prof_steps, "avg_launch_us": round(1e3 * ms / n, 2),
                     "gemm_ms_per_step": round(ms / args.prof_steps, 2),
                     "algorithmic_gflop_per_step": round(flops / args.prof_steps / 1e9, 1)}
@@ -223,9 +237,10 @@ def main():
         out = {
             "metric": "training images/sec (224^2, bs=256/GPU)", "value": round(value, 2), "unit": "images/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"CALM-ViT {args.workload} cls, {S}x{S}x3 synthetic, bs={batch}/GPU, fp32, "
-                                   "fwd+loss+bwd+clip+AdamW", "global_batch": world * batch,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": PRECISION_INFO[args.precision][0],
+            "data": "synthetic",
+            "config": {"workload": f"CALM-ViT {args.workload} cls, {S}x{S}x3 synthetic, bs={batch}/GPU, "
+                                   f"{args.precision} matmuls, fwd+loss+bwd+clip+AdamW", "global_batch": world * batch,
                        "parallelism": f"dp{world}", "loss": float(loss)},
             "model_tflops": round(value * wl["gflop_img"] / 1e3, 2),
             "roofline": roofline,

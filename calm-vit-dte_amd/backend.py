@@ -18,6 +18,24 @@ from ._lib import ACT_GELU, ACT_GELU_BWD, ACT_NONE  # noqa: F401  (re-exported)
 
 SN_EPS = 1e-12
 
+# calm_gemm_args.dtype (include/calm_vit.h): which matrix pipe the GEMMs use.  Tensors are fp32 in every mode.
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
+_precision = "fp32"
+
+
+def set_matmul_precision(name):
+    """'fp32'   exact fp32 MFMA (default; BASELINE config #2, parity 1e-3 rel fp32 with margin 1e3)
+    'bf16'   bf16 operands, fp32 accumulate (autocast(bfloat16) arithmetic; BASELINE configs #3-#5)
+    'bf16x3' bf16 hi/lo split, 3 MFMA passes: fp32-level results (~1e-5) on the bf16 matrix pipe"""
+    global _precision
+    if name not in PRECISIONS:
+        raise ValueError(f"unknown matmul precision {name!r}; choose from {sorted(PRECISIONS)}")
+    _precision = name
+
+
+def get_matmul_precision():
+    return _precision
+
 
 def _ptr(t, allow_none=False):
     if t is None:
@@ -75,7 +93,7 @@ class HipBackend:
         g.accumulate = int(accumulate)
         g.reduce_batch = int(reduce_batch)
         g.split_k = split_k
-        g.dtype = _lib.F32
+        g.dtype = PRECISIONS[_precision]
         _lib.check(self.lib.calm_gemm(C.byref(g), _stream()), "calm_gemm")
 
     # ---- LayerNorm --------------------------------------------------------------------

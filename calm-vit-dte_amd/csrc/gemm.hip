@@ -111,6 +111,53 @@ __device__ __forceinline__ void store_operand(float (*T)[LDT], const float (&reg
     }
 }
 
+// Shared epilogue: acc (32x32 MFMA C layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) ->
+// scale, bias, optional pre-activation store, GELU / GELU', LayerScale, residual, accumulate or atomics.
+template <int MT, int NT>
+__device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][NT], int m0, int n0, int wm, int wn,
+                                              int r, int h, int z) {
+    float scale = p.alpha;
+    if (p.inv_scale) scale = scale / p.inv_scale[0];
+    const int zc = p.atomic ? 0 : z;
+    const int cb0 = zc / p.batch1, cb1 = zc - cb0 * p.batch1;
+    const long coff = cb0 * p.c_b0 + cb1 * p.c_b1;
+    float* __restrict__ Cb = p.C + coff;
+    float* __restrict__ Pb = p.C_pre ? p.C_pre + coff : nullptr;
+    const float* __restrict__ Xb = p.aux ? p.aux + coff : nullptr;
+    const float* __restrict__ Rb = p.residual ? p.residual + cb0 * p.r_b0 + cb1 * p.r_b1 : nullptr;
+
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn * (32 * NT) + 32 * j + r;
+            if (col >= p.N) continue;
+            const float bj = p.bias ? p.bias[col] : 0.f;
+            const float sj = p.col_scale ? p.col_scale[col] : 1.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = m0 + wm * (32 * MT) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (row >= p.M) continue;
+                const long off = (long)row * p.c_rs + col;
+                float v = acc[i][j][e] * scale;
+                if (p.atomic) {
+                    atomicAdd(Cb + off, v);
+                    continue;
+                }
+                v += bj;
+                if (Pb) Pb[off] = v;
+                if (p.act == CALM_ACT_GELU) v = gelu_erf_f(v);
+                else if (p.act == CALM_ACT_GELU_BWD) v *= gelu_erf_grad_f(Xb[off]);
+                v *= sj;
+                if (Rb) v += Rb[(long)row * p.r_rs + col];
+                if (p.accumulate) v += Cb[off];
+                Cb[off] = v;
+            }
+        }
+    }
+}
+
+
 template <bool AKC, bool BKC, int VEC, int BN_>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
     constexpr int WN = BN_ == 128 ? 2 : 1;        // wave grid: 2x2 (128x128 tile) or 4x1 (128x96 tile)
@@ -188,46 +235,201 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
         buf ^= 1;
     }
 
-    // ---- epilogue ----
-    float scale = p.alpha;
-    if (p.inv_scale) scale = scale / p.inv_scale[0];
-    const int zc = p.atomic ? 0 : z;
-    const int cb0 = zc / p.batch1, cb1 = zc - cb0 * p.batch1;
-    const long coff = cb0 * p.c_b0 + cb1 * p.c_b1;
-    float* __restrict__ Cb = p.C + coff;
-    float* __restrict__ Pb = p.C_pre ? p.C_pre + coff : nullptr;
-    const float* __restrict__ Xb = p.aux ? p.aux + coff : nullptr;
-    const float* __restrict__ Rb = p.residual ? p.residual + cb0 * p.r_b0 + cb1 * p.r_b1 : nullptr;
+    gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z);
+}
 
+
+// =====================================================================================================
+// bf16-operand GEMM family: tensors stay fp32 in HBM; operands are converted to bf16 while being staged
+// into LDS and multiplied on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate) with fp32 accumulation.
+//   NPASS == 1: plain bf16 operands                  (what autocast(bfloat16) computes for Linear/matmul)
+//   NPASS == 3: split a = hi + lo (both bf16); acc += hi*hi + hi*lo + lo*hi   ("bf16x3": products accurate to
+//               ~2^-17 relative, i.e. fp32-level results at a fraction of the fp32-MFMA time, because the
+//               kernel is bound by staging fp32 bytes, not by the matrix pipe).
+// k-contiguous operands use a [row][k] LDS image (80-byte rows: conflict-free ds_read_b128 fragments);
+// row-contiguous ("transposed") operands keep their natural [k][row] image (320-byte rows), written with
+// contiguous ds_write_b64 and read as k-contiguous MFMA fragments by ds_read_b64_tr_b16.
+// =====================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int CK = 32;                 // k-tile
+constexpr int KC_LD = 40;              // bf16 per row of a [row][k] image
+constexpr int MC_LD = 160;             // bf16 per k-row of a [k][row] image
+constexpr int PLANE = 128 * KC_LD;     // == 32 * MC_LD bf16 = 10240 B
+
+template <bool KC, int ROWS>
+__device__ __forceinline__ void c_load(const float* __restrict__ base, long rs, long cs, int row0, int nrows_all,
+                                       int k0, int K, f32x4 (&reg)[4]) {
+    const int tid = threadIdx.x;
+    const int nrows = min(nrows_all, row0 + ROWS);
+    if constexpr (KC) {
+        const int k = k0 + 4 * (tid & 7);
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + (tid >> 3) + 32 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < nrows && k < K) v = *reinterpret_cast<const f32x4*>(base + (long)row * rs + k);
+            reg[i] = v;
+        }
+    } else {
+        const int row = row0 + 4 * (tid & 31);
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = n0 + wn * (32 * NT) + 32 * j + r;
-            if (col >= p.N) continue;
-            const float bj = p.bias ? p.bias[col] : 0.f;
-            const float sj = p.col_scale ? p.col_scale[col] : 1.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (32 * MT) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                const long off = (long)row * p.c_rs + col;
-                float v = acc[i][j][e] * scale;
-                if (p.atomic) {
-                    atomicAdd(Cb + off, v);
-                    continue;
-                }
-                v += bj;
-                if (Pb) Pb[off] = v;
-                if (p.act == CALM_ACT_GELU) v = gelu_erf_f(v);
-                else if (p.act == CALM_ACT_GELU_BWD) v *= gelu_erf_grad_f(Xb[off]);
-                v *= sj;
-                if (Rb) v += Rb[(long)row * p.r_rs + col];
-                if (p.accumulate) v += Cb[off];
-                Cb[off] = v;
-            }
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + 4 * (tid >> 5) + j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < nrows && k < K) v = *reinterpret_cast<const f32x4*>(base + (long)k * cs + row);
+            reg[j] = v;
         }
     }
+}
+
+template <int NPASS>
+__device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = (__bf16)v[e];
+        if constexpr (NPASS == 3) lo[e] = (__bf16)(v[e] - (float)hi[e]);
+    }
+}
+
+template <bool KC, int NPASS>
+__device__ __forceinline__ void c_store(__bf16* __restrict__ hi_plane, __bf16* __restrict__ lo_plane,
+                                        const f32x4 (&reg)[4]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bf16x4 hi, lo;
+        split4<NPASS>(reg[i], hi, lo);
+        int off;
+        if constexpr (KC) off = ((tid >> 3) + 32 * i) * KC_LD + 4 * (tid & 7);          // [row][k]
+        else off = (4 * (tid >> 5) + i) * MC_LD + 4 * (tid & 31);                       // [k][row]
+        *reinterpret_cast<bf16x4*>(hi_plane + off) = hi;
+        if constexpr (NPASS == 3) *reinterpret_cast<bf16x4*>(lo_plane + off) = lo;
+    }
+}
+
+// MFMA A/B fragment (8 consecutive k for row `rowbase + (lane&31)`, k = 16*s + 8*(lane>>5) + 0..7)
+template <bool KC>
+__device__ __forceinline__ bf16x8 c_frag(const __bf16* __restrict__ plane, int rowbase, int s, int lane) {
+    if constexpr (KC) {
+        return *reinterpret_cast<const bf16x8*>(plane + (rowbase + (lane & 31)) * KC_LD + 16 * s + 8 * (lane >> 5));
+    } else {
+        // hardware transpose read: each 16-lane group fetches a 4(k) x 16(row) block and gets it column-major
+        const int q = (lane & 15) >> 2, pp = lane & 3, gi = lane >> 4;
+        const __bf16* a0 = plane + (16 * s + 8 * (gi >> 1) + q) * MC_LD + rowbase + 16 * (gi & 1) + 4 * pp;
+        const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(a0));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(a0 + 4 * MC_LD));
+        s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <bool AKC, bool BKC, int NPASS, int BN_>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16c_kernel(const GemmP p) {
+    constexpr int WN = BN_ == 128 ? 2 : 1;
+    constexpr int MT = BN_ == 128 ? 2 : 1;
+    constexpr int NT = BN_ / (WN * 32);
+    constexpr int NPL = NPASS == 3 ? 2 : 1;                     // planes per operand (hi [, lo])
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2][2][NPL][PLANE];   // [stage][A|B][plane]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int tiles = p.tiles_m * p.tiles_n;
+    int lin = blockIdx.x;
+    if (tiles >= 8) {
+        const int q = tiles >> 3, rem = tiles & 7, x = lin & 7, idx = lin >> 3;
+        lin = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + idx;
+    }
+    const int tn = lin % p.tiles_n, tm = lin / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN_;
+    const int z = blockIdx.y;
+    const int kb_begin = z * p.kb_per_z;
+    const int kb_end = min(kb_begin + p.kb_per_z, p.kb_total);
+    if (kb_begin >= kb_end && p.atomic) return;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra[4], rb[4];
+    auto fetch = [&](int kb) {
+        const int b = kb / p.kpb;
+        const int k0 = (kb - b * p.kpb) * CK;
+        const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
+        c_load<AKC, BM>(p.A + b0 * p.a_b0 + b1 * p.a_b1, p.a_rs, p.a_cs, m0, p.M, k0, p.K, ra);
+        c_load<BKC, BN_>(p.B + b0 * p.b_b0 + b1 * p.b_b1, p.b_rs, p.b_cs, n0, p.N, k0, p.K, rb);
+    };
+    auto stash = [&](int st) {
+        c_store<AKC, NPASS>(lds[st][0][0], lds[st][0][NPL - 1], ra);
+        c_store<BKC, NPASS>(lds[st][1][0], lds[st][1][NPL - 1], rb);
+    };
+
+    int buf = 0;
+    if (kb_begin < kb_end) {
+        fetch(kb_begin);
+        stash(0);
+    }
+    __syncthreads();
+
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+        const bool more = kb + 1 < kb_end;
+        if (more) fetch(kb + 1);
+#pragma unroll
+        for (int s = 0; s < CK / 16; ++s) {
+            bf16x8 ah[MT], bh[NT], al[MT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ah[i] = c_frag<AKC>(lds[buf][0][0], wm * (32 * MT) + 32 * i, s, lane);
+                if constexpr (NPASS == 3) al[i] = c_frag<AKC>(lds[buf][0][NPL - 1], wm * (32 * MT) + 32 * i, s, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bh[j] = c_frag<BKC>(lds[buf][1][0], wn * (32 * NT) + 32 * j, s, lane);
+                if constexpr (NPASS == 3) bl[j] = c_frag<BKC>(lds[buf][1][NPL - 1], wn * (32 * NT) + 32 * j, s, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if constexpr (NPASS == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z);
+}
+
+template <bool AKC, bool BKC, int NPASS>
+int launch_c(const GemmP& p, dim3 grid, int bn, hipStream_t s) {
+    if (bn == 128) hipLaunchKernelGGL((gemm_bf16c_kernel<AKC, BKC, NPASS, 128>), grid, dim3(NTHREADS), 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16c_kernel<AKC, BKC, NPASS, 96>), grid, dim3(NTHREADS), 0, s, p);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NPASS>
+int launch_c_layout(const GemmP& p, dim3 grid, int bn, bool akc, bool bkc, hipStream_t s) {
+    if (akc && bkc) return launch_c<true, true, NPASS>(p, grid, bn, s);
+    if (akc && !bkc) return launch_c<true, false, NPASS>(p, grid, bn, s);
+    if (!akc && bkc) return launch_c<false, true, NPASS>(p, grid, bn, s);
+    return launch_c<false, false, NPASS>(p, grid, bn, s);
 }
 
 template <bool AKC, bool BKC, int VEC>
@@ -245,7 +447,7 @@ inline bool mult4(int64_t x) { return (x & 3) == 0; }
 extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return CALM_E_INVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch0 <= 0 || a->batch1 <= 0) return CALM_E_INVAL;
-    if (a->dtype != CALM_F32) return CALM_E_UNSUPP;
+    if (a->dtype != CALM_F32 && a->dtype != CALM_BF16 && a->dtype != CALM_BF16X3) return CALM_E_UNSUPP;
     if (a->a_rs != 1 && a->a_cs != 1) return CALM_E_LAYOUT;
     if (a->b_rs != 1 && a->b_cs != 1) return CALM_E_LAYOUT;
     if (a->act == CALM_ACT_GELU_BWD && !a->aux) return CALM_E_INVAL;
@@ -271,7 +473,16 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     p.tiles_n = (a->N + bn - 1) / bn;
     const int tiles = p.tiles_m * p.tiles_n;
     const int batch = a->batch0 * a->batch1;
-    p.kpb = (a->K + BK - 1) / BK;
+    const bool akc = a->a_cs == 1;
+    const bool bkc = a->b_cs == 1;
+    bool vec = aligned16(a->A) && aligned16(a->B) && mult4(a->a_b0) && mult4(a->a_b1) && mult4(a->b_b0) &&
+               mult4(a->b_b1);
+    vec = vec && (akc ? (mult4(a->K) && mult4(a->a_rs)) : (mult4(a->M) && mult4(a->a_cs)));
+    vec = vec && (bkc ? (mult4(a->K) && mult4(a->b_rs)) : (mult4(a->N) && mult4(a->b_cs)));
+    // bf16-operand kernels need the 16-byte staging path; anything else runs on the exact fp32 kernels
+    const int family = vec ? a->dtype : CALM_F32;
+    const int bk = family == CALM_F32 ? BK : CK;
+    p.kpb = (a->K + bk - 1) / bk;
 
     const bool trivial_epi = !a->bias && !a->col_scale && !a->residual && !a->C_pre && a->act == CALM_ACT_NONE;
     int nsplit = 1;
@@ -310,13 +521,8 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     if (gy > 65535) return CALM_E_UNSUPP;
     dim3 grid(tiles, gy);
 
-    const bool akc = a->a_cs == 1;
-    const bool bkc = a->b_cs == 1;
-    bool vec = aligned16(a->A) && aligned16(a->B) && mult4(a->a_b0) && mult4(a->a_b1) && mult4(a->b_b0) &&
-               mult4(a->b_b1);
-    vec = vec && (akc ? (mult4(a->K) && mult4(a->a_rs)) : (mult4(a->M) && mult4(a->a_cs)));
-    vec = vec && (bkc ? (mult4(a->K) && mult4(a->b_rs)) : (mult4(a->N) && mult4(a->b_cs)));
-
+    if (family == CALM_BF16) return launch_c_layout<1>(p, grid, bn, akc, bkc, s);
+    if (family == CALM_BF16X3) return launch_c_layout<3>(p, grid, bn, akc, bkc, s);
     if (vec) {
         if (akc && bkc) return launch<true, true, 4>(p, grid, bn, s);
         if (akc && !bkc) return launch<true, false, 4>(p, grid, bn, s);

@@ -33,7 +33,11 @@ extern "C" {
 #define CALM_E_LAYOUT  (-2)   /* stride pattern the kernel cannot address     */
 #define CALM_E_UNSUPP  (-3)   /* combination of options not implemented       */
 
-enum { CALM_F32 = 0 };
+/* calm_gemm_args.dtype — tensors are fp32 in memory in every mode; the mode selects the matrix pipe:
+ *   CALM_F32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32), bit-for-bit an fmaf chain
+ *   CALM_BF16   operands rounded to bf16 in LDS, fp32 accumulate (what autocast(bfloat16) computes)
+ *   CALM_BF16X3 operands split hi+lo bf16, 3 MFMA passes, fp32 accumulate: ~2^-17 relative product error */
+enum { CALM_F32 = 0, CALM_BF16 = 1, CALM_BF16X3 = 2 };
 enum { CALM_ACT_NONE = 0, CALM_ACT_GELU = 1, CALM_ACT_GELU_BWD = 2 };
 
 int         calm_abi_version(void);

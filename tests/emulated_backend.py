@@ -33,13 +33,28 @@ class EmuPlan:
 class EmulatedBackend:
     name = "emulated"
 
+    @staticmethod
+    def precision():
+        import calm_vit_dte_amd as calm
+        return calm.backend.get_matmul_precision()
+
     def gemm(self, A, B, Cout, M, N, K, a, b, c, batch=(1, 1), alpha=1.0, inv_scale=None, bias=None,
              col_scale=None, residual=None, r=(0, 0, 0), C_pre=None, aux=None, act=ACT_NONE,
              accumulate=False, reduce_batch=False, split_k=0):
         b0, b1 = batch
         Av = _view(A, (b0, b1, M, K), (a[2], a[3], a[0], a[1]))
         Bv = _view(B, (b0, b1, N, K), (b[2], b[3], b[0], b[1]))
-        acc = torch.matmul(Av, Bv.transpose(-1, -2))
+        prec = self.precision()
+        if prec == "bf16":                                  # operands rounded to bf16, fp32 accumulate
+            Av, Bv = Av.bfloat16().float(), Bv.bfloat16().float()
+            acc = torch.matmul(Av, Bv.transpose(-1, -2))
+        elif prec == "bf16x3":                              # hi/lo split, hi*hi + hi*lo + lo*hi
+            ah, bh = Av.bfloat16().float(), Bv.bfloat16().float()
+            al, bl = (Av - ah).bfloat16().float(), (Bv - bh).bfloat16().float()
+            mm = lambda x, y: torch.matmul(x.double(), y.double().transpose(-1, -2))
+            acc = (mm(ah, bh) + mm(ah, bl) + mm(al, bh)).float()
+        else:
+            acc = torch.matmul(Av, Bv.transpose(-1, -2))
         scale = alpha / inv_scale if inv_scale is not None else alpha
         if reduce_batch:
             acc = acc.sum(dim=(0, 1), keepdim=True)
