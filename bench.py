@@ -120,6 +120,27 @@ class GemmProfiler:
         return flops, ms, len(self.records)
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
+    (profiles/*pmc_summary.csv: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes,
+    scripts/gpu_pmc.sh) — the counters cannot be read from inside this process."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.csv")))
+    if not files:
+        return None
+    n = rd = wr = 0.0
+    for r in csv.DictReader(open(files[-1])):
+        if r["kernel"].startswith(kernel_prefix):
+            n += float(r["dispatches"])
+            rd += float(r["hbm_read_bytes(2xFETCH)"])
+            wr += float(r["hbm_write_bytes"])
+    if not n:
+        return None
+    return {"hbm_bytes_per_launch": round((rd + wr) / n), "read": round(rd / n), "write": round(wr / n),
+            "source": os.path.relpath(files[-1], ROOT)}
+
+
 def cpu_baseline(wl, budget_s=25.0):
     """CPU oracle (port of the reference path) fwd+bwd+AdamW on a bounded sample of the workload."""
     from oracle import calm_oracle as O
@@ -226,7 +247,8 @@ def main():
         _, peak, klabel = PRECISION_INFO[args.precision]
         roofline = {"bound": "mfma", "kernel": klabel,
                     "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "frac": round(achieved / peak, 4),
+                    "traffic": pmc_traffic("gemm_f32_kernel" if args.precision == "fp32" else "gemm_bf16c_kernel"),
                     "launches_per_step": n // args.prof_steps, "avg_launch_us": round(1e3 * ms / n, 2),
                     "gemm_ms_per_step": round(ms / args.prof_steps, 2),
                     "algorithmic_gflop_per_step": round(flops / args.prof_steps / 1e9, 1)}
