@@ -27,7 +27,7 @@ def _setup_path():
             sys.path.insert(0, p)
 
 
-def _run_steps(rank, world, x, y, steps, bucket_mb):
+def _run_steps(rank, world, x, y, steps, bucket_mb, stock_ddp=False):
     from importlib import import_module
     import calm_vit_dte_amd as calm
     from emulated_backend import EmulatedBackend
@@ -40,17 +40,25 @@ def _run_steps(rank, world, x, y, steps, bucket_mb):
             for p in m.parameters():
                 p.add_(0.01)
     with calm.backend.use_backend(EmulatedBackend()):
-        trainer.sync_module_states(m)
-        opt = trainer.make_optimizer(m)
-        red = trainer.BucketedGradReducer(m, bucket_mb=bucket_mb) if world > 1 else None
-        step = trainer.TrainStep(m, opt, red)
+        if stock_ddp:
+            # exactly what the reference's train() does (distributed_trainer_cls.py:55)
+            from torch.nn.parallel import DistributedDataParallel as DDP
+            wrapped = DDP(m)
+            opt = trainer.make_optimizer(m)
+            step = trainer.TrainStep(wrapped, opt, None)
+            step.params = [p for p in m.parameters() if p.requires_grad]
+        else:
+            trainer.sync_module_states(m)
+            opt = trainer.make_optimizer(m)
+            red = trainer.BucketedGradReducer(m, bucket_mb=bucket_mb) if world > 1 else None
+            step = trainer.TrainStep(m, opt, red)
         n = x.shape[0] // world
         xs, ys = x[rank * n:(rank + 1) * n], y[rank * n:(rank + 1) * n]
         losses = [float(step(xs, ys)[0]) for _ in range(steps)]
     return m, losses
 
 
-def _worker(rank, world, port, x, y, steps, outdir):
+def _worker(rank, world, port, x, y, steps, outdir, stock_ddp=False):
     _setup_path()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -59,21 +67,22 @@ def _worker(rank, world, port, x, y, steps, outdir):
     trainer = import_module("calm_vit_dte_amd.trainer")
     r, lr, w = trainer.init_distributed(use_gpu=False)
     assert (r, w) == (rank, world)
-    m, losses = _run_steps(rank, world, x, y, steps, bucket_mb=1)     # 1 MiB buckets -> several buckets
+    m, losses = _run_steps(rank, world, x, y, steps, bucket_mb=1, stock_ddp=stock_ddp)   # 1 MiB buckets -> several
     torch.save({"sd": m.state_dict(), "losses": losses}, os.path.join(outdir, f"rank{rank}.pt"))
     import torch.distributed as dist
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-def test_two_rank_gloo_training_matches_single_process(tmp_path):
+@pytest.mark.parametrize("stock_ddp", [False, True], ids=["bucketed_reducer", "torch_DDP_wrapper"])
+def test_two_rank_gloo_training_matches_single_process(tmp_path, stock_ddp):
     _setup_path()
     import numpy as np
     g = np.random.default_rng(0)
     x = torch.from_numpy(g.standard_normal((8, 3, 32, 32)).astype(np.float32))          # bs=8, CIFAR-shaped
     y = torch.nn.functional.one_hot(torch.from_numpy(g.integers(0, 10, 8)), 10).float() * 0.9 + 0.01
     steps = 2
-    mp.spawn(_worker, args=(2, _free_port(), x, y, steps, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), x, y, steps, str(tmp_path), stock_ddp), nprocs=2, join=True)
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
     r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
     for k in r0["sd"]:
