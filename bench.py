@@ -38,6 +38,10 @@ WORKLOADS = {
                              seq_len_step=16, seq_len_reduce=40, out_features=1000), gflop_img=46.063, batch=256),
     "base224": dict(kw=dict(heads=12, seq_length=224, in_features=672, dim_step=48, mean_var_hidden=240,
                             seq_len_step=16, seq_len_reduce=80, out_features=1000), gflop_img=48.359, batch=256),
+    "base384": dict(kw=dict(heads=12, seq_length=384, in_features=1152, dim_step=48, mean_var_hidden=240,
+                            seq_len_step=16, seq_len_reduce=80, out_features=1000), gflop_img=356.425, batch=32),
+    "large224": dict(kw=dict(heads=6, seq_length=224, in_features=672, dim_step=24, mean_var_hidden=480,
+                             seq_len_step=8, seq_len_reduce=160, out_features=1000), gflop_img=92.167, batch=128),
     "nano48": dict(kw=dict(heads=3, seq_length=48, in_features=144, dim_step=12, mean_var_hidden=24,
                            seq_len_step=4, seq_len_reduce=16, out_features=10), gflop_img=0.500, batch=64),
 }

@@ -93,32 +93,6 @@ __device__ __forceinline__ void tr_store(const Regs<NV>& rg, float* __restrict__
         }
     }
 }
-// block of 16 rows x `cols` columns staged as is: dst[r][col], zero-filled up to cols_pad
-template <int NT, int NV>
-__device__ __forceinline__ void rm_load(Regs<NV>& rg, const float* __restrict__ src, long stride, int cols, int cols_pad) {
-    constexpr int nt = NT;
-    const int per_row = cols_pad >> 2;
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-        const int f = threadIdx.x + u * nt;
-        const int r = f / per_row, cq = f - r * per_row;
-        f32x4v val = {0.f, 0.f, 0.f, 0.f};
-        if (r < 16 && 4 * cq < cols) val = *reinterpret_cast<const f32x4v*>(src + (long)r * stride + 4 * cq);
-        rg.v[u] = val;
-    }
-}
-template <int NT, int NV>
-__device__ __forceinline__ void rm_store(const Regs<NV>& rg, float* __restrict__ dst, int ld, int cols_pad) {
-    constexpr int nt = NT;
-    const int per_row = cols_pad >> 2;
-#pragma unroll
-    for (int u = 0; u < NV; ++u) {
-        const int f = threadIdx.x + u * nt;
-        const int r = f / per_row, cq = f - r * per_row;
-        if (r < 16) *reinterpret_cast<f32x4v*>(dst + r * ld + 4 * cq) = rg.v[u];
-    }
-}
-
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 template <int NJ, int NW>

@@ -1,7 +1,9 @@
-// calm_gemm: strided / batched / split-K fp32 GEMM with fused epilogue for gfx950.
+// calm_gemm: strided / batched / split-K GEMM with fused epilogue for gfx950 (fp32 tensors).
+// Two kernel families share tiling, remap, split logic and epilogue: the exact fp32 MFMA family below and the
+// bf16-operand family (gemm_bf16c_kernel) further down.
 //
-// Tile 128x128x16 per 256-thread workgroup (4 waves as 2x2, each 64x64 = 2x2 v_mfma_f32_32x32x2_f32
-// accumulators).  Both operands are staged K-MAJOR in LDS ([k][row], row stride 132 floats): fragment
+// Tile 128x128x16 (4 waves as 2x2, each 64x64 = 2x2 v_mfma_f32_32x32x2_f32 accumulators) or 128x96x16 (4x1 waves,
+// 1x3 accumulators) per 256-thread workgroup.  Both operands are staged K-MAJOR in LDS ([k][row], row stride 132 floats): fragment
 // reads are then one conflict-free ds_read_b32 per MFMA operand for every source layout, and the
 // four source layouts (k- or row-contiguous A and B) only differ in the global->register->LDS
 // staging.  fp32 MFMA issues every 64 cycles per SIMD, so LDS/VALU work hides under it; the loop is
@@ -12,7 +14,7 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132, NTHREADS = 256;
+constexpr int BM = 128, BK = 16, LDT = 132, NTHREADS = 256;
 
 struct GemmP {
     const float* A; const float* B; float* C;

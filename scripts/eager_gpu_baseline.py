@@ -15,6 +15,7 @@ from oracle import calm_oracle as O
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=256)
 ap.add_argument("--steps", type=int, default=4)
+ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--autocast", action="store_true", help="bf16 autocast, as the reference trainer (cls:84)")
 a = ap.parse_args()
 cfg = O.ViTConfig(heads=6, seq_length=224, in_features=672, dim_step=48, mean_var_hidden=120, seq_len_step=16,
@@ -41,7 +42,7 @@ def step():
     return loss
 
 
-for _ in range(2):
+for _ in range(a.warmup):
     step()
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):

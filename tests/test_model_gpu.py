@@ -123,6 +123,16 @@ def test_bottleneck_cross_block_hd20():
     _block_vs_oracle(12, 240, 240, 240, 80, 80, 80, True)
 
 
+def test_plain_block_base384_long_stripes_hd96():
+    """BASELINE config #4 (S=384: 24 key tiles, no fused instantiation -> composite attention path)."""
+    _block_vs_oracle(12, 1152, 1152, 240, 384, 80, 384, False, B=1)
+
+
+def test_latent_cross_block_large224_672_to_600_hd100():
+    """BASELINE config #5 (dim_step=24: S 224 -> 200, not a multiple of 16 -> composite attention path)."""
+    _block_vs_oracle(6, 672, 600, 480, 224, 160, 200, True, B=1)
+
+
 def _small224(device):
     cfg = CONFIGS["small224_cls"]
     m = calm.ViT(torch.device("cpu"), type=8, heads=cfg.heads, seq_length=224, in_features=672, dim_step=48,
