@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcalmvit_hip.so")
+# CALM_VIT_LIB: A/B another build of the same library (kernel tuning); never a different implementation
+LIB_PATH = os.environ.get("CALM_VIT_LIB") or os.path.join(HERE, "libcalmvit_hip.so")
 
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 F32 = 0

@@ -194,14 +194,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    // 32x32 sub-tiles of this wave that intersect the problem (edge tiles of M=672/528-sized outputs)
-    bool live[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            live[i][j] = (m0 + wm * (32 * MT) + 32 * i < p.M) && (n0 + wn * (32 * NT) + 32 * j < p.N);
-
     float ra[8], rb[8];
 
     auto fetch = [&](int kb) {
@@ -235,8 +227,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
-                    if (live[i][j])      // wave-uniform: sub-tiles entirely outside M x N issue no MFMA
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         if (more) {
             store_operand<AKC, VEC>(As[buf ^ 1], ra);
@@ -373,13 +364,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16c_kernel(const GemmP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    bool live[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-            live[i][j] = (m0 + wm * (32 * MT) + 32 * i < p.M) && (n0 + wn * (32 * NT) + 32 * j < p.N);
-
     f32x4 ra[4], rb[4];
     auto fetch = [&](int kb) {
         const int b = kb / p.kpb;
@@ -420,7 +404,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16c_kernel(const GemmP p) {
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
-                    if (!live[i][j]) continue;
                     if constexpr (NPASS == 3) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);

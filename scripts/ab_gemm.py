@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Time key calm_gemm shapes (median of N, HIP events).  A/B two builds on the SAME box:
+   CALM_VIT_LIB=/path/libA.so python3 scripts/ab_gemm.py ; CALM_VIT_LIB=/path/libB.so python3 scripts/ab_gemm.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import calm_vit_dte_amd as calm
+
+be = calm.backend.get_backend()
+prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+calm.backend.set_matmul_precision(prec)
+
+
+def t_med(fn, n=12, warm=3):
+    for _ in range(warm): fn()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record(); fn(); b.record()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in ev)
+    return t[len(t) // 2]
+
+
+g = lambda *s: torch.randn(*s, device="cuda")
+tot = 0.0
+print(os.environ.get("CALM_VIT_LIB", "default lib"), prec)
+for M, N, K in ((57344, 672, 672), (57344, 1344, 672), (57344, 672, 1344), (45056, 528, 528), (32768, 384, 384), (20480, 240, 240)):
+    x, w, y = g(M, K), g(N, K), g(M, N)
+    fwd = t_med(lambda: be.gemm(x, w, y, M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), split_k=1))
+    dgr = t_med(lambda: be.gemm(y, w, x, M, K, N, (N, 1, 0, 0), (1, K, 0, 0), (K, 0, 0), split_k=1))
+    G = g(N, K)
+    wgr = t_med(lambda: be.gemm(y, x, G, N, K, M, (1, N, 0, 0), (1, K, 0, 0), (K, 0, 0)))
+    fl = 2.0 * M * N * K / 1e9
+    tot += fwd + dgr + wgr
+    print(f"M={M:6d} N={N:5d} K={K:5d}: fwd {fwd:7.3f} ms {fl/fwd:6.1f} TF | dgrad {dgr:7.3f} ms {fl/dgr:6.1f} TF | wgrad {wgr:7.3f} ms {fl/wgr:6.1f} TF")
+B, H, S, hd = 256, 6, 224, 112
+D = H * hd
+q, k, P = g(B, S, D), g(B, S, D), g(B, H, S, S)
+t = t_med(lambda: be.gemm(q, k, P, S, S, hd, (D, 1, S * D, hd), (D, 1, S * D, hd), (S, H * S * S, S * S), batch=(B, H)))
+print(f"batched logits 224x224x112 x1536: {t:7.3f} ms {2.0*S*S*hd*B*H/1e9/t:6.1f} TF")
+print(f"sum {tot + t:.3f} ms")
