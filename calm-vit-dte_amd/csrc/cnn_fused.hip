@@ -5,15 +5,18 @@
 // HBM traffic is the 3-channel input and output only (24 B/pixel forward, 36 B/pixel backward): the
 // 32-channel hidden maps live in LDS for one 16x16 pixel tile (+halo) and are RECOMPUTED in backward
 // instead of being stored (the unfused form wrote/read four [B,S,S,32] maps: ~1 KB/pixel).  The work is
-// VALU (erf-GELU) bound; thread = (channel c = tid&31, pixel group g = tid>>5), so LDS accesses of a
-// 32-lane half are 32 consecutive floats (conflict-free), and the channel reductions of the two 1x1 convs
-// go through an LDS image re-read with the thread = pixel mapping.
+// instruction-issue bound (measured: a cheaper erf changed nothing), so a thread owns a channel PAIR:
+// 8-byte LDS accesses and packed fp32 math halve the instruction count.  The channel reductions of the two
+// 1x1 convs go through an LDS image re-read with the thread = pixel mapping.
 #include "common.h"
 
 namespace {
 
 constexpr int CH = 32;          // hidden channels of proj
 constexpr int T = 16;           // tile edge (pixels)
+constexpr int PS = CH + 2;      // LDS floats per pixel (even: 8-byte aligned channel pairs; 34 spreads adjacent pixels over banks)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct CnnW {
     const float* w0; const float* s0; const float* b0;   // [32,3]  (/sigma0), [32]
@@ -21,24 +24,34 @@ struct CnnW {
     const float* w4; const float* s4; const float* b4;   // [3,32]  (/sigma4), [3]
 };
 
+__device__ __forceinline__ f32x2 gelu2(f32x2 z) { return (f32x2){gelu_erf_f(z[0]), gelu_erf_f(z[1])}; }
+__device__ __forceinline__ f32x2 gelu2_grad(f32x2 z) { return (f32x2){gelu_erf_grad_f(z[0]), gelu_erf_grad_f(z[1])}; }
+__device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
+__device__ __forceinline__ void st2(float* p, f32x2 v) { *reinterpret_cast<f32x2*>(p) = v; }
+
+// Thread = (channel pair c2 = tid&15 -> channels 2*c2, 2*c2+1 ; pixel group g = tid>>4): every LDS access of the
+// hidden maps is one 8-byte ds_read/ds_write per lane and the per-channel math is packed (v_pk_fma_f32).
+
 // ------------------------------------------------------------------------------------------ forward
 constexpr int FW_NT = 256;
+constexpr int FG = FW_NT / 16;  // 16 pixel groups
 constexpr int FH = T + 2;       // h1 region edge (halo 1)
 
 __global__ __launch_bounds__(FW_NT) void cnn_fwd_kernel(const float* __restrict__ x, CnnW W, float* __restrict__ out,
                                                         int B, int S, int tiles_per_side, long n_tiles) {
     __shared__ float xs[FH * FH * 3];
-    __shared__ float hs[FH * FH * CH];        // h1 on the 18x18 region; later h2 on the 16x16 tile, stride 33
+    __shared__ __attribute__((aligned(16))) float hs[FH * FH * PS];   // h1 on 18x18; later h2 on the 16x16 tile
     __shared__ float w4s[3 * CH + 3];
 
-    const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
+    const int tid = threadIdx.x, c2 = tid & 15, g = tid >> 4;
+    const int c = 2 * c2;
     const float i0 = 1.0f / W.s0[0], i2 = 1.0f / W.s2[0], i4 = 1.0f / W.s4[0];
-    float w0r[3], w2r[9];
+    f32x2 w0r[3], w2r[9];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) w0r[i] = W.w0[c * 3 + i] * i0;
+    for (int i = 0; i < 3; ++i) w0r[i] = (f32x2){W.w0[c * 3 + i], W.w0[(c + 1) * 3 + i]} * i0;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w2r[k] = W.w2[c * 9 + k] * i2;
-    const float b0r = W.b0[c], b2r = W.b2[c];
+    for (int k = 0; k < 9; ++k) w2r[k] = (f32x2){W.w2[c * 9 + k], W.w2[(c + 1) * 9 + k]} * i2;
+    const f32x2 b0r = {W.b0[c], W.b0[c + 1]}, b2r = {W.b2[c], W.b2[c + 1]};
     if (tid < 3 * CH) w4s[tid] = W.w4[tid] * i4;
     if (tid < 3) w4s[3 * CH + tid] = W.b4[tid];
 
@@ -54,28 +67,28 @@ __global__ __launch_bounds__(FW_NT) void cnn_fwd_kernel(const float* __restrict_
             xs[e] = (yy >= 0 && yy < S && xx >= 0 && xx < S) ? xb[((long)yy * S + xx) * 3 + ch] : 0.f;
         }
         __syncthreads();
-        for (int p = g; p < FH * FH; p += FW_NT / 32) {
+        for (int p = g; p < FH * FH; p += FG) {
             const int yy = y0 - 1 + p / FH, xx = x0 - 1 + p % FH;
             const bool in = yy >= 0 && yy < S && xx >= 0 && xx < S;
-            const float z = w0r[0] * xs[3 * p] + w0r[1] * xs[3 * p + 1] + w0r[2] * xs[3 * p + 2] + b0r;
-            hs[p * CH + c] = in ? gelu_erf_f(z) : 0.f;   // zero padding applies to the dwconv INPUT
+            const f32x2 z = w0r[0] * xs[3 * p] + w0r[1] * xs[3 * p + 1] + w0r[2] * xs[3 * p + 2] + b0r;
+            st2(&hs[p * PS + c], in ? gelu2(z) : (f32x2){0.f, 0.f});   // zero padding applies to the dwconv INPUT
         }
         __syncthreads();
-        float h2[T * T / (FW_NT / 32)];
+        f32x2 h2[T * T / FG];
 #pragma unroll
-        for (int k = 0; k < T * T / (FW_NT / 32); ++k) {
-            const int q = g + (FW_NT / 32) * k;
+        for (int k = 0; k < T * T / FG; ++k) {
+            const int q = g + FG * k;
             const int qy = q / T, qx = q % T;
-            float acc = b2r;
+            f32x2 acc = b2r;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) acc += w2r[ky * 3 + kx] * hs[((qy + ky) * FH + qx + kx) * CH + c];
-            h2[k] = gelu_erf_f(acc);
+                for (int kx = 0; kx < 3; ++kx) acc += w2r[ky * 3 + kx] * ld2(&hs[((qy + ky) * FH + qx + kx) * PS + c]);
+            h2[k] = gelu2(acc);
         }
         __syncthreads();                                   // everyone done reading h1
 #pragma unroll
-        for (int k = 0; k < T * T / (FW_NT / 32); ++k) hs[(g + (FW_NT / 32) * k) * (CH + 1) + c] = h2[k];
+        for (int k = 0; k < T * T / FG; ++k) st2(&hs[(g + FG * k) * PS + c], h2[k]);
         __syncthreads();
         {
             const int q = tid, qy = q / T, qx = q % T;
@@ -83,9 +96,11 @@ __global__ __launch_bounds__(FW_NT) void cnn_fwd_kernel(const float* __restrict_
             if (yy < S && xx < S) {
                 float o0 = w4s[3 * CH], o1 = w4s[3 * CH + 1], o2 = w4s[3 * CH + 2];
 #pragma unroll
-                for (int cc = 0; cc < CH; ++cc) {
-                    const float h = hs[q * (CH + 1) + cc];
-                    o0 += w4s[cc] * h; o1 += w4s[CH + cc] * h; o2 += w4s[2 * CH + cc] * h;
+                for (int cc = 0; cc < CH; cc += 2) {
+                    const f32x2 h = ld2(&hs[q * PS + cc]);
+                    o0 += w4s[cc] * h[0] + w4s[cc + 1] * h[1];
+                    o1 += w4s[CH + cc] * h[0] + w4s[CH + cc + 1] * h[1];
+                    o2 += w4s[2 * CH + cc] * h[0] + w4s[2 * CH + cc + 1] * h[1];
                 }
                 const int pc = ((qy + 1) * FH + qx + 1) * 3;
                 float* ob = out + ((long)b * S * S + (long)yy * S + xx) * 3;
@@ -97,7 +112,7 @@ __global__ __launch_bounds__(FW_NT) void cnn_fwd_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------ backward
 constexpr int BW_NT = 512;
-constexpr int BG = BW_NT / 32;   // 16 pixel groups
+constexpr int BG = BW_NT / 16;   // 32 pixel groups
 constexpr int H2 = T + 4;        // h1 region edge (halo 2) = 20
 constexpr int H1 = T + 2;        // dh2p region edge (halo 1) = 18
 
@@ -109,25 +124,30 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
                                                         long n_tiles) {
     __shared__ float xs[H2 * H2 * 3];
     __shared__ float dys[H1 * H1 * 3];
-    __shared__ float h1s[H2 * H2 * CH];       // h1 on 20x20; later dh1p on the tile with stride 33
-    __shared__ float d2s[H1 * H1 * CH];       // dL/d(h2 pre-activation) on 18x18
-    __shared__ float wts[3 * CH * 2];         // w4 (by [o][c]) and w0 (by [c][i]) / sigma
+    __shared__ __attribute__((aligned(16))) float h1s[H2 * H2 * PS];   // h1 on 20x20; later dh1p on the tile
+    __shared__ __attribute__((aligned(16))) float d2s[H1 * H1 * PS];   // dL/d(h2 pre-activation) on 18x18
+    __shared__ float wts[3 * CH];                                       // w0 (by [c][i]) / sigma
     __shared__ float red[BG * CH];
 
-    const int tid = threadIdx.x, c = tid & 31, g = tid >> 5;
+    const int tid = threadIdx.x, c2 = tid & 15, g = tid >> 4;
+    const int c = 2 * c2;
     const float i0 = 1.0f / W.s0[0], i2 = 1.0f / W.s2[0], i4 = 1.0f / W.s4[0];
-    float w0r[3], w2r[9], w4r[3];
+    f32x2 w0r[3], w2r[9], w4r[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { w0r[i] = W.w0[c * 3 + i] * i0; w4r[i] = W.w4[i * CH + c] * i4; }
+    for (int i = 0; i < 3; ++i) {
+        w0r[i] = (f32x2){W.w0[c * 3 + i], W.w0[(c + 1) * 3 + i]} * i0;
+        w4r[i] = (f32x2){W.w4[i * CH + c], W.w4[i * CH + c + 1]} * i4;
+    }
 #pragma unroll
-    for (int k = 0; k < 9; ++k) w2r[k] = W.w2[c * 9 + k] * i2;
-    const float b0r = W.b0[c], b2r = W.b2[c];
-    if (tid < 3 * CH) { wts[tid] = W.w4[tid] * i4; wts[3 * CH + tid] = W.w0[tid] * i0; }
+    for (int k = 0; k < 9; ++k) w2r[k] = (f32x2){W.w2[c * 9 + k], W.w2[(c + 1) * 9 + k]} * i2;
+    const f32x2 b0r = {W.b0[c], W.b0[c + 1]}, b2r = {W.b2[c], W.b2[c + 1]};
+    if (tid < 3 * CH) wts[tid] = W.w0[tid] * i0;
 
-    float a_g4[3] = {0.f, 0.f, 0.f}, a_g2[9], a_gb2 = 0.f, a_g0[3] = {0.f, 0.f, 0.f}, a_gb0 = 0.f;
+    const f32x2 zero2 = {0.f, 0.f};
+    f32x2 a_g4[3] = {zero2, zero2, zero2}, a_g2[9], a_gb2 = zero2, a_g0[3] = {zero2, zero2, zero2}, a_gb0 = zero2;
     float a_gb4[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 9; ++k) a_g2[k] = 0.f;
+    for (int k = 0; k < 9; ++k) a_g2[k] = zero2;
 
     for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const int b = (int)(tile / (tiles_per_side * tiles_per_side));
@@ -151,8 +171,8 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
         for (int p = g; p < H2 * H2; p += BG) {
             const int yy = y0 - 2 + p / H2, xx = x0 - 2 + p % H2;
             const bool in = yy >= 0 && yy < S && xx >= 0 && xx < S;
-            const float z = w0r[0] * xs[3 * p] + w0r[1] * xs[3 * p + 1] + w0r[2] * xs[3 * p + 2] + b0r;
-            h1s[p * CH + c] = in ? gelu_erf_f(z) : 0.f;
+            const f32x2 z = w0r[0] * xs[3 * p] + w0r[1] * xs[3 * p + 1] + w0r[2] * xs[3 * p + 2] + b0r;
+            st2(&h1s[p * PS + c], in ? gelu2(z) : zero2);
         }
         __syncthreads();
         // dL/dh2p on the 18x18 region (+ weight grads of conv4 / dwconv on the tile's own pixels)
@@ -160,45 +180,45 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
             const int ry = r / H1, rx = r % H1;
             const int yy = y0 - 1 + ry, xx = x0 - 1 + rx;
             const bool in = yy >= 0 && yy < S && xx >= 0 && xx < S;
-            float h1v[9];
-            float z = b2r;
+            f32x2 h1v[9];
+            f32x2 z = b2r;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    h1v[ky * 3 + kx] = h1s[((ry + ky) * H2 + rx + kx) * CH + c];
+                    h1v[ky * 3 + kx] = ld2(&h1s[((ry + ky) * H2 + rx + kx) * PS + c]);
                     z += w2r[ky * 3 + kx] * h1v[ky * 3 + kx];
                 }
             const float d0 = dys[3 * r], d1 = dys[3 * r + 1], d2 = dys[3 * r + 2];
-            const float dh2 = w4r[0] * d0 + w4r[1] * d1 + w4r[2] * d2;
-            const float dz = in ? dh2 * gelu_erf_grad_f(z) : 0.f;
-            d2s[r * CH + c] = dz;
+            const f32x2 dh2 = w4r[0] * d0 + w4r[1] * d1 + w4r[2] * d2;
+            const f32x2 dz = in ? dh2 * gelu2_grad(z) : zero2;
+            st2(&d2s[r * PS + c], dz);
             const bool own = in && ry >= 1 && ry <= T && rx >= 1 && rx <= T;
             if (own) {
-                const float h2 = gelu_erf_f(z);
-                a_g4[0] += d0 * h2; a_g4[1] += d1 * h2; a_g4[2] += d2 * h2;
+                const f32x2 h2 = gelu2(z);
+                a_g4[0] += h2 * d0; a_g4[1] += h2 * d1; a_g4[2] += h2 * d2;
                 a_gb2 += dz;
 #pragma unroll
                 for (int k = 0; k < 9; ++k) a_g2[k] += dz * h1v[k];
             }
         }
         __syncthreads();                                   // d2s complete, h1s no longer read
-        // dL/dh1p on the tile; staged (stride 33) over the h1 image for the channel reduction of conv0^T
+        // dL/dh1p on the tile; staged over the h1 image for the channel reduction of conv0^T
         for (int q = g; q < T * T; q += BG) {
             const int qy = q / T, qx = q % T;
             const int yy = y0 + qy, xx = x0 + qx;
             const bool in = yy < S && xx < S;
-            float dh1 = 0.f;
+            f32x2 dh1 = zero2;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx)
-                    dh1 += w2r[ky * 3 + kx] * d2s[((qy + 2 - ky) * H1 + qx + 2 - kx) * CH + c];
+                    dh1 += w2r[ky * 3 + kx] * ld2(&d2s[((qy + 2 - ky) * H1 + qx + 2 - kx) * PS + c]);
             const int px = ((qy + 2) * H2 + qx + 2) * 3;
             const float x0v = xs[px], x1v = xs[px + 1], x2v = xs[px + 2];
-            const float z = w0r[0] * x0v + w0r[1] * x1v + w0r[2] * x2v + b0r;
-            const float dz = in ? dh1 * gelu_erf_grad_f(z) : 0.f;
-            h1s[q * (CH + 1) + c] = dz;
+            const f32x2 z = w0r[0] * x0v + w0r[1] * x1v + w0r[2] * x2v + b0r;
+            const f32x2 dz = in ? dh1 * gelu2_grad(z) : zero2;
+            st2(&h1s[q * PS + c], dz);
             a_gb0 += dz;
             a_g0[0] += dz * x0v; a_g0[1] += dz * x1v; a_g0[2] += dz * x2v;
         }
@@ -211,9 +231,11 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
                 float o0 = dys[pd], o1 = dys[pd + 1], o2 = dys[pd + 2];
                 a_gb4[0] += o0; a_gb4[1] += o1; a_gb4[2] += o2;
 #pragma unroll
-                for (int cc = 0; cc < CH; ++cc) {
-                    const float d = h1s[q * (CH + 1) + cc];
-                    o0 += wts[3 * CH + cc * 3] * d; o1 += wts[3 * CH + cc * 3 + 1] * d; o2 += wts[3 * CH + cc * 3 + 2] * d;
+                for (int cc = 0; cc < CH; cc += 2) {
+                    const f32x2 d = ld2(&h1s[q * PS + cc]);
+                    o0 += wts[cc * 3] * d[0] + wts[cc * 3 + 3] * d[1];
+                    o1 += wts[cc * 3 + 1] * d[0] + wts[cc * 3 + 4] * d[1];
+                    o2 += wts[cc * 3 + 2] * d[0] + wts[cc * 3 + 5] * d[1];
                 }
                 float* ob = dx + ((long)b * S * S + (long)yy * S + xx) * 3;
                 ob[0] = o0; ob[1] = o1; ob[2] = o2;
@@ -221,25 +243,26 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
         }
     }
     // ---- block reduction of the weight-gradient accumulators, one atomic per element per block ----
-    auto reduce_c = [&](float v, float* dst) {             // sum over the 16 pixel groups for channel c
+    auto reduce_c = [&](f32x2 v, float* dst0, int stride) {   // sum over the 32 pixel groups for channels c, c+1
         __syncthreads();
-        red[g * CH + c] = v;
+        red[g * CH + c] = v[0];
+        red[g * CH + c + 1] = v[1];
         __syncthreads();
-        if (g == 0) {
+        if (tid < CH) {
             float s = 0.f;
 #pragma unroll
-            for (int k = 0; k < BG; ++k) s += red[k * CH + c];
-            atomicAdd(dst, s);
+            for (int k = 0; k < BG; ++k) s += red[k * CH + tid];
+            atomicAdd(dst0 + tid * stride, s);
         }
     };
 #pragma unroll
-    for (int o = 0; o < 3; ++o) reduce_c(a_g4[o], g4 + o * CH + c);
+    for (int o = 0; o < 3; ++o) reduce_c(a_g4[o], g4 + o * CH, 1);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) reduce_c(a_g2[k], g2 + c * 9 + k);
-    reduce_c(a_gb2, gb2 + c);
+    for (int k = 0; k < 9; ++k) reduce_c(a_g2[k], g2 + k, 9);
+    reduce_c(a_gb2, gb2, 1);
 #pragma unroll
-    for (int i = 0; i < 3; ++i) reduce_c(a_g0[i], g0 + c * 3 + i);
-    reduce_c(a_gb0, gb0 + c);
+    for (int i = 0; i < 3; ++i) reduce_c(a_g0[i], g0 + i, 3);
+    reduce_c(a_gb0, gb0, 1);
 #pragma unroll
     for (int o = 0; o < 3; ++o) {
         __syncthreads();
