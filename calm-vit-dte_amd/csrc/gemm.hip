@@ -14,7 +14,11 @@
 
 namespace {
 
-constexpr int BM = 128, BK = 16, LDT = 132, NTHREADS = 256;
+#ifndef CALM_GEMM_BK
+#define CALM_GEMM_BK 16          // k-tile of the fp32 family (A/B'd: 16 vs 32)
+#endif
+constexpr int BM = 128, BK = CALM_GEMM_BK, LDT = 132, NTHREADS = 256;
+constexpr int NREG = BK / 2;     // staging floats per thread per operand (128 rows x BK / 256 threads)
 
 struct GemmP {
     const float* A; const float* B; float* C;
@@ -37,15 +41,16 @@ struct GemmP {
 
 template <bool KC, int VEC, int ROWS>
 __device__ __forceinline__ void load_operand(const float* __restrict__ base, long rs, long cs, int row0,
-                                             int nrows_all, int k0, int K, float (&reg)[8]) {
+                                             int nrows_all, int k0, int K, float (&reg)[NREG]) {
     const int tid = threadIdx.x;
     const int nrows = min(nrows_all, row0 + ROWS);       // rows of THIS tile only
     if constexpr (VEC == 4) {
         if constexpr (KC) {
-            const int k = k0 + 4 * (tid & 3);
+            constexpr int KQ = BK / 4, RPP = NTHREADS / KQ;       // float4 per row, rows per pass
+            const int k = k0 + 4 * (tid % KQ);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = row0 + (tid >> 2) + 64 * i;
+            for (int i = 0; i < NREG / 4; ++i) {
+                const int row = row0 + (tid / KQ) + RPP * i;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (row < nrows && k < K) v = *reinterpret_cast<const f32x4*>(base + (long)row * rs + k);
                 reg[4 * i + 0] = v[0]; reg[4 * i + 1] = v[1]; reg[4 * i + 2] = v[2]; reg[4 * i + 3] = v[3];
@@ -53,7 +58,7 @@ __device__ __forceinline__ void load_operand(const float* __restrict__ base, lon
         } else {
             const int row = row0 + 4 * (tid & 31);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NREG / 4; ++i) {
                 const int k = k0 + (tid >> 5) + 8 * i;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
                 if (row < nrows && k < K) v = *reinterpret_cast<const f32x4*>(base + (long)k * cs + row);
@@ -62,16 +67,16 @@ __device__ __forceinline__ void load_operand(const float* __restrict__ base, lon
         }
     } else {
         if constexpr (KC) {
-            const int k = k0 + (tid & 15);
+            const int k = k0 + (tid % BK);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = row0 + (tid >> 4) + 16 * i;
+            for (int i = 0; i < NREG; ++i) {
+                const int row = row0 + (tid / BK) + (NTHREADS / BK) * i;
                 reg[i] = (row < nrows && k < K) ? base[(long)row * rs + k] : 0.f;
             }
         } else {
             const int row = row0 + (tid & 127);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < NREG; ++i) {
                 const int k = k0 + (tid >> 7) + 2 * i;
                 reg[i] = (row < nrows && k < K) ? base[(long)k * cs + row] : 0.f;
             }
@@ -80,21 +85,22 @@ __device__ __forceinline__ void load_operand(const float* __restrict__ base, lon
 }
 
 template <bool KC, int VEC>
-__device__ __forceinline__ void store_operand(float (*T)[LDT], const float (&reg)[8]) {
+__device__ __forceinline__ void store_operand(float (*T)[LDT], const float (&reg)[NREG]) {
     const int tid = threadIdx.x;
     if constexpr (VEC == 4) {
         if constexpr (KC) {
-            const int kq = 4 * (tid & 3);
+            constexpr int KQ = BK / 4, RPP = NTHREADS / KQ;
+            const int kq = 4 * (tid % KQ);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int row = (tid >> 2) + 64 * i;
+            for (int i = 0; i < NREG / 4; ++i) {
+                const int row = (tid / KQ) + RPP * i;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) T[kq + j][row] = reg[4 * i + j];
             }
         } else {
             const int row = 4 * (tid & 31);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < NREG / 4; ++i) {
                 const int k = (tid >> 5) + 8 * i;
                 f32x4 v = {reg[4 * i + 0], reg[4 * i + 1], reg[4 * i + 2], reg[4 * i + 3]};
                 *reinterpret_cast<f32x4*>(&T[k][row]) = v;
@@ -102,13 +108,13 @@ __device__ __forceinline__ void store_operand(float (*T)[LDT], const float (&reg
         }
     } else {
         if constexpr (KC) {
-            const int k = tid & 15;
+            const int k = tid % BK;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) T[k][(tid >> 4) + 16 * i] = reg[i];
+            for (int i = 0; i < NREG; ++i) T[k][(tid / BK) + (NTHREADS / BK) * i] = reg[i];
         } else {
             const int row = tid & 127;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) T[(tid >> 7) + 2 * i][row] = reg[i];
+            for (int i = 0; i < NREG; ++i) T[(tid >> 7) + 2 * i][row] = reg[i];
         }
     }
 }
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    float ra[8], rb[8];
+    float ra[NREG], rb[NREG];
 
     auto fetch = [&](int kb) {
         const int b = kb / p.kpb;
