@@ -367,6 +367,266 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnFwdP p) {
     }
 }
 
+// =====================================================================================================
+// Backward of the attention core, two kernels with the same tiling/staging as the forward and NO cross-wave
+// reductions (the mask-MLP backward and the dR terms stay GEMMs):
+//   Q side  (queries on the lanes, one wave = 16 queries, all keys on the accumulator rows)
+//       dP^T[j,i] = sum_d V_h[j,d] dO_h[i,d]          (same loop as QK^T: V in the K role, dO in the Q role)
+//       delta_i   = sum_j P[i,j] dP[i,j]               (in-lane + 2 shuffles)
+//       dS        = P o (dP - delta)                   -> written once to HBM for the K/V side
+//       dM       += dS                                 (summed over heads in registers)
+//       dQ^T[d,i] = scale sum_j K_h[j,d] dS^T[j,i]     (same block as PV: K_h stripe in the V role)
+//   KV side (keys on the lanes, one wave = 16 keys, all queries on the accumulator rows)
+//       dV^T[d,j] = sum_i dO_h[i,d] P[i,j]             (PV block: dO_h stripe, P tiles as B operand)
+//       dK^T[d,j] = scale sum_i Q_h[i,d] dS[i,j]       (PV block: Q_h stripe, dS tiles as B operand)
+// =====================================================================================================
+struct AttnBwdP {
+    const float* q; const float* k; const float* v; const float* dout;
+    const float* P;              // [B,H,Sq,Skv] probabilities saved by the forward
+    float* dS;                   // [B,H,Sq,Skv] written by the Q side, read by the KV side
+    float* dq; float* dk; float* dv;
+    float* dM;                   // [B,Sq,Skv]
+    int B, Sq, Skv, H, hd;
+    float scale;
+};
+
+template <int NJ, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(const AttnBwdP p) {
+    constexpr int NTH = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int SKV = 16 * NJ;
+    constexpr int LDJ = SKV + ((SKV % 32 == 16) ? 0 : 16);
+    constexpr int TQ = 16 * NW;
+    constexpr int LDQ = TQ + ((TQ % 32 == 16) ? 0 : 16);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int q0 = blockIdx.x * TQ;
+    const int nq = min(TQ, p.Sq - q0);
+    const bool active = 16 * wave < nq;
+    const int iq = q0 + 16 * wave + r16;
+    const int D = p.H * p.hd;
+    const int hd = p.hd;
+    const int DT = (hd + 15) / 16, hdp = 16 * DT, LDV = hdp + 4;
+    auto bufK = [&](int i) { return smem + i * 16 * LDJ; };
+    auto bufQ = [&](int i) { return smem + 32 * LDJ + i * 16 * LDQ; };
+    float* bufV = smem + 32 * LDJ + 32 * LDQ;                   // whole K_h stripe for the dQ block
+    const int v_per_row = hdp >> 2, v_total = SKV * v_per_row;
+    const int nchq = (hd + 15) / 16;
+    const int v_share = (v_total + nchq - 1) / nchq;
+
+    const float* dob = p.dout + ((long)b * p.Sq + q0) * D;
+    const float* kb = p.k + (long)b * p.Skv * D;
+    const float* vb = p.v + (long)b * p.Skv * D;
+
+    f32x4v accM[NJ];
+#pragma unroll
+    for (int t = 0; t < NJ; ++t) accM[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll 1
+    for (int h = 0; h < p.H; ++h) {
+        const float* doh = dob + h * hd;
+        const float* kh = kb + h * hd;
+        const float* vh = vb + h * hd;
+        f32x4v accD[NJ];
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) accD[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        {
+            Regs<NV_K> rk; Regs<NV_Q> rq; Regs<NV_K> rv;
+            auto s_load = [&](int c) {                         // K_h stripe, a share per chunk iteration
+#pragma unroll
+                for (int u = 0; u < NV_K; ++u) {
+                    const int f = c * v_share + tid + u * NTH;
+                    const int row = f / v_per_row, cq = f - row * v_per_row;
+                    f32x4v val = {0.f, 0.f, 0.f, 0.f};
+                    if (tid + u * NTH < v_share && f < v_total && 4 * cq < hd)
+                        val = *reinterpret_cast<const f32x4v*>(kh + (long)row * D + 4 * cq);
+                    rv.v[u] = val;
+                }
+            };
+            auto s_store = [&](int c) {
+#pragma unroll
+                for (int u = 0; u < NV_K; ++u) {
+                    const int f = c * v_share + tid + u * NTH;
+                    const int row = f / v_per_row, cq = f - row * v_per_row;
+                    if (tid + u * NTH < v_share && f < v_total)
+                        *reinterpret_cast<f32x4v*>(bufV + row * LDV + 4 * cq) = rv.v[u];
+                }
+            };
+            km_load<NTH>(rk, vh, D, SKV, 0, hd);
+            km_load<NTH>(rq, doh, D, nq, 0, hd);
+            km_store<NTH>(rk, bufK(0), LDJ, SKV);
+            km_store<NTH>(rq, bufQ(0), LDQ, nq);
+            __syncthreads();
+#pragma unroll 1
+            for (int c = 0; c < nchq; ++c) {
+                const int cur = c & 1;
+                s_load(c);
+                if (c + 1 < nchq) {
+                    km_load<NTH>(rk, vh, D, SKV, 16 * (c + 1), hd);
+                    km_load<NTH>(rq, doh, D, nq, 16 * (c + 1), hd);
+                }
+                if (active) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const float bq = bufQ(cur)[(4 * s + g) * LDQ + 16 * wave + r16];
+#pragma unroll
+                        for (int t = 0; t < NJ; ++t)
+                            accD[t] = MFMA16(bufK(cur)[(4 * s + g) * LDJ + 16 * t + r16], bq, accD[t]);
+                    }
+                }
+                s_store(c);
+                if (c + 1 < nchq) {
+                    km_store<NTH>(rk, bufK(cur ^ 1), LDJ, SKV);
+                    km_store<NTH>(rq, bufQ(cur ^ 1), LDQ, nq);
+                }
+                __syncthreads();
+            }
+        }
+        // delta, dS = P o (dP - delta); P is read twice (second time from L2) instead of being held in registers
+        const long prow = (((long)b * p.H + h) * p.Sq + (active ? iq : q0)) * p.Skv;
+        float part = 0.f;
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) {
+            const f32x4v pv = *reinterpret_cast<const f32x4v*>(p.P + prow + 16 * t + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) part += pv[r] * accD[t][r];
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) {
+            const f32x4v pv = *reinterpret_cast<const f32x4v*>(p.P + prow + 16 * t + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) accD[t][r] = pv[r] * (accD[t][r] - part);
+            accM[t] = accM[t] + accD[t];
+            if (active) *reinterpret_cast<f32x4v*>(p.dS + prow + 16 * t + 4 * g) = accD[t];
+        }
+        // dQ^T[d,i] = scale * sum_j K_h[j,d] dS^T[j,i]
+        if (active) {
+            float* qrow = p.dq + ((long)b * p.Sq + iq) * D + h * hd;
+#pragma unroll 1
+            for (int d = 0; d < DT; d += 2) {
+                f32x4v accO = {0.f, 0.f, 0.f, 0.f}, accO2 = {0.f, 0.f, 0.f, 0.f};
+                const float* kcol = bufV + 16 * d + r16;
+                const int d2 = (d + 1 < DT) ? 16 : 0;
+#pragma unroll
+                for (int t = 0; t < NJ; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        accO = MFMA16(kcol[(16 * t + 4 * g + r) * LDV], accD[t][r], accO);
+                        accO2 = MFMA16(kcol[(16 * t + 4 * g + r) * LDV + d2], accD[t][r], accO2);
+                    }
+                if (16 * d + 4 * g < hd) *reinterpret_cast<f32x4v*>(qrow + 16 * d + 4 * g) = accO * p.scale;
+                if (d + 1 < DT && 16 * (d + 1) + 4 * g < hd)
+                    *reinterpret_cast<f32x4v*>(qrow + 16 * (d + 1) + 4 * g) = accO2 * p.scale;
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        float* mrow = p.dM + ((long)b * p.Sq + iq) * p.Skv;
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) *reinterpret_cast<f32x4v*>(mrow + 16 * t + 4 * g) = accM[t];
+    }
+}
+
+// NI = query tiles (accumulator rows), one wave = 16 keys on the lanes
+template <int NI, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(const AttnBwdP p) {
+    constexpr int NTH = 64 * NW;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int SQ = 16 * NI;
+    constexpr int TK = 16 * NW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y;
+    const int k0 = blockIdx.x * TK;
+    const int nk = min(TK, p.Skv - k0);
+    const bool active = 16 * wave < nk;
+    const int jk = k0 + 16 * wave + r16;                        // this lane's key
+    const int D = p.H * p.hd;
+    const int hd = p.hd;
+    const int DT = (hd + 15) / 16, hdp = 16 * DT, LDV = hdp + 4;
+    float* bufV = smem;                                         // whole dO_h / Q_h stripe [Sq][LDV]
+    const int v_per_row = hdp >> 2, v_total = SQ * v_per_row;
+    const float* qb = p.q + (long)b * p.Sq * D;
+    const float* dob = p.dout + (long)b * p.Sq * D;
+
+    auto stage = [&](const float* src) {                        // [Sq x hd] stripe (row stride D) -> bufV
+        for (int f = tid; f < v_total; f += NTH) {
+            const int row = f / v_per_row, cq = f - row * v_per_row;
+            f32x4v val = {0.f, 0.f, 0.f, 0.f};
+            if (4 * cq < hd) val = *reinterpret_cast<const f32x4v*>(src + (long)row * D + 4 * cq);
+            *reinterpret_cast<f32x4v*>(bufV + row * LDV + 4 * cq) = val;
+        }
+    };
+    auto contract = [&](const f32x4v (&X)[NI], float* out_row, float scale) {   // out^T[d,j] = sum_i stripe[i,d] X[i,j]
+#pragma unroll 1
+        for (int d = 0; d < DT; d += 2) {
+            f32x4v accO = {0.f, 0.f, 0.f, 0.f}, accO2 = {0.f, 0.f, 0.f, 0.f};
+            const float* col = bufV + 16 * d + r16;
+            const int d2 = (d + 1 < DT) ? 16 : 0;
+#pragma unroll
+            for (int t = 0; t < NI; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    accO = MFMA16(col[(16 * t + 4 * g + r) * LDV], X[t][r], accO);
+                    accO2 = MFMA16(col[(16 * t + 4 * g + r) * LDV + d2], X[t][r], accO2);
+                }
+            if (16 * d + 4 * g < hd) *reinterpret_cast<f32x4v*>(out_row + 16 * d + 4 * g) = accO * scale;
+            if (d + 1 < DT && 16 * (d + 1) + 4 * g < hd)
+                *reinterpret_cast<f32x4v*>(out_row + 16 * (d + 1) + 4 * g) = accO2 * scale;
+        }
+    };
+
+#pragma unroll 1
+    for (int h = 0; h < p.H; ++h) {
+        const long base = ((long)b * p.H + h) * p.Sq * p.Skv + (active ? jk : k0);
+        f32x4v X[NI];
+        // P tiles [i rows, key lanes]: 16 consecutive keys = one 64-byte segment per row
+#pragma unroll
+        for (int t = 0; t < NI; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[t][r] = p.P[base + (long)(16 * t + 4 * g + r) * p.Skv];
+        stage(dob + h * hd);
+        __syncthreads();
+        if (active) contract(X, p.dv + ((long)b * p.Skv + jk) * D + h * hd, 1.0f);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NI; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X[t][r] = p.dS[base + (long)(16 * t + 4 * g + r) * p.Skv];
+        stage(qb + h * hd);
+        __syncthreads();
+        if (active) contract(X, p.dk + ((long)b * p.Skv + jk) * D + h * hd, p.scale);
+        __syncthreads();
+    }
+}
+
+template <int NJ, int NW>
+int launch_bwd(const AttnBwdP& p, hipStream_t s) {
+    const int tiles = p.Sq / 16;
+    const int TQ = 16 * NW, SKV = 16 * NJ;
+    const int LDJ = SKV + ((SKV % 32 == 16) ? 0 : 16);
+    const int LDQ = TQ + ((TQ % 32 == 16) ? 0 : 16);
+    const int hdp = (p.hd + 15) / 16 * 16, LDV = hdp + 4;
+    const size_t lds_q = sizeof(float) * (size_t)(32 * LDJ + 32 * LDQ + SKV * LDV);
+    const size_t lds_kv = sizeof(float) * (size_t)(SKV * LDV);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel<NJ, NW>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_q);
+    if (e != hipSuccess) return (int)e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv_kernel<NJ, NW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_kv);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((tiles + NW - 1) / NW, p.B);
+    hipLaunchKernelGGL((attn_bwd_q_kernel<NJ, NW>), grid, dim3(64 * NW), lds_q, s, p);
+    CALM_LAUNCH_CHECK();
+    hipLaunchKernelGGL((attn_bwd_kv_kernel<NJ, NW>), grid, dim3(64 * NW), lds_kv, s, p);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
 inline int pick_waves(int tiles) {
     const int groups = (tiles + 7) / 8;
     return (tiles + groups - 1) / groups;
@@ -430,6 +690,25 @@ int calm_attention_fwd(const float* q, const float* k, const float* v, const flo
         case 8: return launch_fwd<8, 8>(p, s);
         case 11: return launch_fwd<11, 6>(p, s);
         case 14: return launch_fwd<14, 7>(p, s);
+    }
+    return CALM_E_UNSUPP;
+}
+
+int calm_attention_bwd(const float* q, const float* k, const float* v, const float* dout, const float* P, float* dS,
+                       float* dq, float* dk, float* dv, float* dM, int32_t B, int32_t Sq, int32_t Skv, int32_t H,
+                       int32_t hd, void* stream) {
+    if (!q || !k || !v || !dout || !P || !dS || !dq || !dk || !dv || !dM || B <= 0) return CALM_E_INVAL;
+    if (!calm_attention_fwd_supported(Sq, Skv, H, hd)) return CALM_E_UNSUPP;
+    if (B > 65535) return CALM_E_UNSUPP;
+    AttnBwdP p{q, k, v, dout, P, dS, dq, dk, dv, dM, B, Sq, Skv, H, hd, 1.0f / sqrtf((float)hd)};
+    hipStream_t s = as_stream(stream);
+    switch (Skv / 16) {
+        case 2: return launch_bwd<2, 2>(p, s);
+        case 3: return launch_bwd<3, 3>(p, s);
+        case 5: return launch_bwd<5, 5>(p, s);
+        case 8: return launch_bwd<8, 8>(p, s);
+        case 11: return launch_bwd<11, 6>(p, s);
+        case 14: return launch_bwd<14, 7>(p, s);
     }
     return CALM_E_UNSUPP;
 }

@@ -332,20 +332,22 @@ class LatentMaskAttentionFn(Function):
         dout = _c(dout)
         dev, dt = q.device, q.dtype
         pb = (H * Sq * Skv, Sq * Skv)
-        # dP = dO V^T ; dV = P^T dO
         dP = torch.empty_like(P)
-        be.gemm(dout, v, dP, Sq, Skv, hd, (D, 1, Sq * D, hd), (D, 1, Skv * D, hd), (Skv,) + pb, batch=(B, H))
-        dv = torch.empty_like(v)
-        be.gemm(P, dout, dv, Skv, hd, Sq, (1, Skv) + pb, (1, D, Sq * D, hd), (D, Skv * D, hd), batch=(B, H))
-        be.softmax_bwd(P, dP, B * H * Sq, Skv)                 # dP now holds dL
+        dv, dq, dk = torch.empty_like(v), torch.empty_like(q), torch.empty_like(k)
         dM = torch.empty(B * Sq, Skv, dtype=dt, device=dev)
-        be.sum_heads(dP, dM, B, H, Sq * Skv)
-        dq = torch.empty_like(q)
-        be.gemm(dP, k, dq, Sq, hd, Skv, (Skv, 1) + pb, (1, D, Skv * D, hd), (D, Sq * D, hd), batch=(B, H),
-                alpha=scale)
-        dk = torch.empty_like(k)
-        be.gemm(dP, q, dk, Skv, hd, Sq, (1, Skv) + pb, (1, D, Sq * D, hd), (D, Skv * D, hd), batch=(B, H),
-                alpha=scale)
+        if be.attn_fwd_supported(Sq, Skv, H, hd):
+            # fused core: dP, softmax backward, head-sum of dS and the four per-head products in two launches
+            be.attn_bwd(q, k, v, dout, P, dP, dq, dk, dv, dM, B, Sq, Skv, H, hd)
+        else:
+            # dP = dO V^T ; dV = P^T dO
+            be.gemm(dout, v, dP, Sq, Skv, hd, (D, 1, Sq * D, hd), (D, 1, Skv * D, hd), (Skv,) + pb, batch=(B, H))
+            be.gemm(P, dout, dv, Skv, hd, Sq, (1, Skv) + pb, (1, D, Sq * D, hd), (D, Skv * D, hd), batch=(B, H))
+            be.softmax_bwd(P, dP, B * H * Sq, Skv)                 # dP now holds dL
+            be.sum_heads(dP, dM, B, H, Sq * Skv)
+            be.gemm(dP, k, dq, Sq, hd, Skv, (Skv, 1) + pb, (1, D, Skv * D, hd), (D, Sq * D, hd), batch=(B, H),
+                    alpha=scale)
+            be.gemm(dP, q, dk, Skv, hd, Sq, (1, Skv) + pb, (1, D, Sq * D, hd), (D, Skv * D, hd), batch=(B, H),
+                    alpha=scale)
         # mask MLP backward
         G2 = torch.empty_like(w2)
         _lin_wgrad(be, dM, hg, G2)

@@ -140,6 +140,15 @@ int calm_attention_fwd(const float* q, const float* k, const float* v, const flo
                        float* hp, float* hg, float* Mk, float* P, int32_t B, int32_t Sq, int32_t Skv, int32_t H, int32_t hd,
                        void* stream);
 
+/* Backward of the attention core for the same shapes (two launches: query side, key/value side):
+ *   dP = dO_h V_h^T; dS = P o (dP - rowsum(P o dP)); dM = sum_h dS; dQ_h = dS K_h / sqrt(hd);
+ *   dV_h = P^T dO_h; dK_h = dS^T Q_h / sqrt(hd).
+ * dS:[B,H,Sq,Skv] is scratch written and re-read by the call; dq,dk,dv,dM are written (not accumulated).
+ * The mask-MLP backward (through dM) and the dR = dM-path terms are calm_gemm calls of the caller. */
+int calm_attention_bwd(const float* q, const float* k, const float* v, const float* dout, const float* P, float* dS,
+                       float* dq, float* dk, float* dv, float* dM, int32_t B, int32_t Sq, int32_t Skv, int32_t H,
+                       int32_t hd, void* stream);
+
 /* ---------------------------------------------------------------------------------------
  * Latent bottleneck sampling (Vi_Tools:232-242) + KL partial sum (Vi_Tools:24-25).
  * mv: [rows, 2*mvh] (mean | raw).  std = softplus(raw)+1e-6;  z = mean + noise*std (noise NULL

@@ -169,6 +169,19 @@ class EmulatedBackend:
         if P is not None:
             P.view(B, H, Sq, Skv).copy_(prob)
 
+    def attn_bwd(self, q, k, v, dout, P, dS, dq, dk, dv, dM, B, Sq, Skv, H, hd):
+        D = H * hd
+        sc = 1.0 / math.sqrt(hd)
+        qh, kh, vh, doh = (t.view(B, -1, H, hd).transpose(1, 2) for t in (q, k, v, dout))
+        Pv = P.view(B, H, Sq, Skv)
+        dP = doh @ vh.transpose(-1, -2)
+        ds = Pv * (dP - (Pv * dP).sum(dim=-1, keepdim=True))
+        dS.view(B, H, Sq, Skv).copy_(ds)
+        dM.view(B, Sq, Skv).copy_(ds.sum(dim=1))
+        dq.view(B, Sq, D).copy_(((ds @ kh) * sc).transpose(1, 2).reshape(B, Sq, D))
+        dk.view(B, Skv, D).copy_(((ds.transpose(-1, -2) @ qh) * sc).transpose(1, 2).reshape(B, Skv, D))
+        dv.view(B, Skv, D).copy_((Pv.transpose(-1, -2) @ doh).transpose(1, 2).reshape(B, Skv, D))
+
     def latent_fwd(self, mv, noise, z, std, kl_sum, rows, mvh):
         m2 = mv.reshape(rows, 2 * mvh)
         mean, raw = m2[:, :mvh], m2[:, mvh:]

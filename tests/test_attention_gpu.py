@@ -54,6 +54,25 @@ def test_fused_attention_forward(B, S, H, hd):
     assert torch.allclose(outs[1][5].sum(dim=-1).cpu(), torch.ones(B, H, S), atol=1e-5)   # rows of P sum to 1
 
 
+@pytest.mark.parametrize("B,S,H,hd", SHAPES)
+def test_fused_attention_backward_core(B, S, H, hd):
+    """dP / softmax backward / head-sum / dQ, dK, dV in the two fused launches vs the emulation."""
+    hip, emu = calm.backend.get_backend(), EmulatedBackend()
+    D = H * hd
+    q, k, v = rnd(B, S, D, seed=1) * 0.5, rnd(B, S, D, seed=2) * 0.5, rnd(B, S, D, seed=3)
+    dout = rnd(B, S, D, seed=8)
+    P = torch.softmax(rnd(B, H, S, S, seed=9) * 2, dim=-1)
+    outs = []
+    for be, dev in ((emu, "cpu"), (hip, "cuda")):
+        t = [x.to(dev) for x in (q, k, v, dout, P)]
+        e = lambda *s: torch.full(s, float("nan"), device=dev)
+        dS, dq, dk, dv, dM = e(B, H, S, S), e(B, S, D), e(B, S, D), e(B, S, D), e(B, S, S)
+        be.attn_bwd(*t, dS, dq, dk, dv, dM, B, S, S, H, hd)
+        outs.append((dS, dq, dk, dv, dM))
+    for name, a, b in zip(("dS", "dq", "dk", "dv", "dM"), outs[1], outs[0]):
+        assert rel_err(a, b) < TOL, name
+
+
 def test_fused_attention_without_probability_output():
     hip = calm.backend.get_backend()
     B, S, H, hd = 2, 80, 6, 40
