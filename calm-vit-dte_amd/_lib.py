@@ -60,6 +60,7 @@ SIGNATURES = {
     "calm_sum_heads": (_i32, [_p, _p, _i32, _i32, _i64, _p]),
     "calm_attention_fwd_supported": (_i32, [_i32, _i32, _i32, _i32]),
     "calm_attention_fwd": (_i32, [_p] * 15 + [_i32] * 5 + [_p]),
+    "calm_attention_bwd_preferred": (_i32, [_i32, _i32, _i32, _i32]),
     "calm_attention_bwd": (_i32, [_p] * 10 + [_i32] * 5 + [_p]),
     "calm_latent_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _p]),
     "calm_latent_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p]),

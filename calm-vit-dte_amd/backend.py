@@ -133,6 +133,9 @@ class HipBackend:
                                                _ptr(b2), _ptr(s2), _ptr(out), _ptr(R), _ptr(hp), _ptr(hg),
                                                _ptr(Mk), _ptr(P, True), B, Sq, Skv, H, hd, _stream()), "calm_attention_fwd")
 
+    def attn_bwd_preferred(self, Sq, Skv, H, hd):
+        return bool(self.lib.calm_attention_bwd_preferred(Sq, Skv, H, hd))
+
     def attn_bwd(self, q, k, v, dout, P, dS, dq, dk, dv, dM, B, Sq, Skv, H, hd):
         _lib.check(self.lib.calm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(dout), _ptr(P), _ptr(dS), _ptr(dq),
                                                _ptr(dk), _ptr(dv), _ptr(dM), B, Sq, Skv, H, hd, _stream()),

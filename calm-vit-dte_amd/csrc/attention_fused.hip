@@ -31,7 +31,6 @@ struct AttnFwdP {
     float scale;
 };
 
-constexpr int NV_K = 2;   // float4 per thread for a [Skv x 16] chunk (needs Skv <= 32*NW)
 constexpr int NV_Q = 1;   // ... for a [16*NW x 16] query chunk
 
 // ---- staging helpers (all threads of the block cooperate) -------------------------------------
@@ -98,6 +97,7 @@ __device__ __forceinline__ void tr_store(const Regs<NV>& rg, float* __restrict__
 template <int NJ, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnFwdP p) {
     constexpr int NTH = 64 * NW;
+    constexpr int NV_K = (NJ + NW - 1) / NW;   // float4 per thread for a [16*NJ x 16] chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int SKV = 16 * NJ;
     constexpr int LDJ = SKV + ((SKV % 32 == 16) ? 0 : 16);    // [c][j] images: 4 lane groups 16 banks apart
@@ -393,6 +393,7 @@ struct AttnBwdP {
 template <int NJ, int NW>
 __global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(const AttnBwdP p) {
     constexpr int NTH = 64 * NW;
+    constexpr int NV_K = (NJ + NW - 1) / NW;   // float4 per thread for a [16*NJ x 16] chunk
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int SKV = 16 * NJ;
     constexpr int LDJ = SKV + ((SKV % 32 == 16) ? 0 : 16);
@@ -627,7 +628,11 @@ int launch_bwd(const AttnBwdP& p, hipStream_t s) {
     return 0;
 }
 
+#ifndef ATT_NW11
+#define ATT_NW11 6     // waves per workgroup for the 11-tile (S=176) instantiation; A/B'd against 4
+#endif
 inline int pick_waves(int tiles) {
+    if (tiles == 11) return ATT_NW11;
     const int groups = (tiles + 7) / 8;
     return (tiles + groups - 1) / groups;
 }
@@ -665,7 +670,6 @@ int calm_attention_fwd_supported(int32_t Sq, int32_t Skv, int32_t H, int32_t hd)
     if (!(nj == 2 || nj == 3 || nj == 5 || nj == 8 || nj == 11 || nj == 14)) return 0;
     // staging registers: a [Skv x 16] chunk is 4*Skv float4 (NV_K per thread), a [16 x hd_pad] V chunk 4*hd_pad
     const int nt = 64 * pick_waves(Sq / 16);
-    if (4 * Skv > NV_K * nt) return 0;
     const int hdp = (hd + 15) / 16 * 16, ldj = Skv + ((Skv % 32 == 16) ? 0 : 16), tq = nt / 4;
     const int ldq = tq + ((tq % 32 == 16) ? 0 : 16);
     if ((32 * ldj + 32 * ldq + Skv * (hdp + 4)) * 4 > 160 * 1024) return 0;   // whole V_h must fit in LDS
@@ -688,10 +692,17 @@ int calm_attention_fwd(const float* q, const float* k, const float* v, const flo
         case 3: return launch_fwd<3, 3>(p, s);
         case 5: return launch_fwd<5, 5>(p, s);
         case 8: return launch_fwd<8, 8>(p, s);
-        case 11: return launch_fwd<11, 6>(p, s);
+        case 11: return launch_fwd<11, ATT_NW11>(p, s);
         case 14: return launch_fwd<14, 7>(p, s);
     }
     return CALM_E_UNSUPP;
+}
+
+// Measured on MI355X (scripts/ab_attn_bwd.py, same process): the two fused launches beat the GEMM composition
+// for head dims <= 64 (S=128/80 stages of Small-224, every stage of Base-224: 1.1-1.7x) and tie or lose above
+// (hd 112: 1.00x, hd 88: 0.76x), where the per-head GEMMs already fill 128-wide tiles.
+int calm_attention_bwd_preferred(int32_t Sq, int32_t Skv, int32_t H, int32_t hd) {
+    return calm_attention_fwd_supported(Sq, Skv, H, hd) && hd <= 64;
 }
 
 int calm_attention_bwd(const float* q, const float* k, const float* v, const float* dout, const float* P, float* dS,
@@ -707,7 +718,7 @@ int calm_attention_bwd(const float* q, const float* k, const float* v, const flo
         case 3: return launch_bwd<3, 3>(p, s);
         case 5: return launch_bwd<5, 5>(p, s);
         case 8: return launch_bwd<8, 8>(p, s);
-        case 11: return launch_bwd<11, 6>(p, s);
+        case 11: return launch_bwd<11, ATT_NW11>(p, s);
         case 14: return launch_bwd<14, 7>(p, s);
     }
     return CALM_E_UNSUPP;

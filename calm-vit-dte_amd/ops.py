@@ -335,8 +335,9 @@ class LatentMaskAttentionFn(Function):
         dP = torch.empty_like(P)
         dv, dq, dk = torch.empty_like(v), torch.empty_like(q), torch.empty_like(k)
         dM = torch.empty(B * Sq, Skv, dtype=dt, device=dev)
-        if be.attn_fwd_supported(Sq, Skv, H, hd):
+        if be.attn_bwd_preferred(Sq, Skv, H, hd):
             # fused core: dP, softmax backward, head-sum of dS and the four per-head products in two launches
+            # (taken where it is measured faster than the composition below: head dims <= 64)
             be.attn_bwd(q, k, v, dout, P, dP, dq, dk, dv, dM, B, Sq, Skv, H, hd)
         else:
             # dP = dO V^T ; dV = P^T dO

@@ -145,6 +145,7 @@ int calm_attention_fwd(const float* q, const float* k, const float* v, const flo
  *   dV_h = P^T dO_h; dK_h = dS^T Q_h / sqrt(hd).
  * dS:[B,H,Sq,Skv] is scratch written and re-read by the call; dq,dk,dv,dM are written (not accumulated).
  * The mask-MLP backward (through dM) and the dR = dM-path terms are calm_gemm calls of the caller. */
+int calm_attention_bwd_preferred(int32_t Sq, int32_t Skv, int32_t H, int32_t hd);   /* supported AND measured faster */
 int calm_attention_bwd(const float* q, const float* k, const float* v, const float* dout, const float* P, float* dS,
                        float* dq, float* dk, float* dv, float* dM, int32_t B, int32_t Sq, int32_t Skv, int32_t H,
                        int32_t hd, void* stream);

@@ -169,6 +169,9 @@ class EmulatedBackend:
         if P is not None:
             P.view(B, H, Sq, Skv).copy_(prob)
 
+    def attn_bwd_preferred(self, Sq, Skv, H, hd):
+        return self.attn_fwd_supported(Sq, Skv, H, hd) and hd <= 64
+
     def attn_bwd(self, q, k, v, dout, P, dS, dq, dk, dv, dM, B, Sq, Skv, H, hd):
         D = H * hd
         sc = 1.0 / math.sqrt(hd)
