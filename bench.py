@@ -240,22 +240,27 @@ def main():
 
     # dominant-kernel roofline: HIP events around every calm_gemm launch of prof_steps extra steps
     roofline = None
-    if rank == 0 and args.prof_steps > 0:
-        with GemmProfiler(calm.backend.get_backend()) as prof:
-            for _ in range(args.prof_steps):
-                step(x, y)
+    if args.prof_steps > 0:
+        # every rank runs the profiled steps (they contain the gradient all-reduce); only rank 0 records
+        prof = GemmProfiler(calm.backend.get_backend()) if rank == 0 else None
+        if prof is not None:
+            prof.__enter__()
+        for _ in range(args.prof_steps):
+            step(x, y)
+        if prof is not None:
+            prof.__exit__()
             flops, ms, n = prof.summary()
             if args.gemm_report:
                 prof.report(args.gemm_report, args.prof_steps)
-        achieved = flops / (ms * 1e-3) / 1e12
-        _, peak, klabel = PRECISION_INFO[args.precision]
-        roofline = {"bound": "mfma", "kernel": klabel,
-                    "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4),
-                    "traffic": pmc_traffic("gemm_f32_kernel" if args.precision == "fp32" else "gemm_bf16c_kernel"),
-                    "launches_per_step": n // args.prof_steps, "avg_launch_us": round(1e3 * ms / n, 2),
-                    "gemm_ms_per_step": round(ms / args.prof_steps, 2),
-                    "algorithmic_gflop_per_step": round(flops / args.prof_steps / 1e9, 1)}
+            achieved = flops / (ms * 1e-3) / 1e12
+            _, peak, klabel = PRECISION_INFO[args.precision]
+            roofline = {"bound": "mfma", "kernel": klabel,
+                        "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                        "frac": round(achieved / peak, 4),
+                        "traffic": pmc_traffic("gemm_f32_kernel" if args.precision == "fp32" else "gemm_bf16c_kernel"),
+                        "launches_per_step": n // args.prof_steps, "avg_launch_us": round(1e3 * ms / n, 2),
+                        "gemm_ms_per_step": round(ms / args.prof_steps, 2),
+                        "algorithmic_gflop_per_step": round(flops / args.prof_steps / 1e9, 1)}
     if world > 1:
         dist.barrier()
 
