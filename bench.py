@@ -192,6 +192,7 @@ def main():
                     help="matrix pipe of the GEMMs (tensors stay fp32): exact fp32 MFMA (default, config #2), "
                          "bf16 operands (autocast arithmetic, configs #3-5), or the fp32-accurate bf16x3 split")
     ap.add_argument("--prof-steps", type=int, default=1)
+    ap.add_argument("--graph", action="store_true", help="capture the whole step into a hipGraph (N=1 only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-report", default="", help="write a per-shape GEMM table (csv) from the profiled steps")
     args = ap.parse_args()
@@ -213,10 +214,17 @@ def main():
     calm.backend.set_matmul_precision(args.precision)
     model = build_model(calm, wl["kw"], device).train()
     trainer.sync_module_states(model)
-    opt = trainer.make_optimizer(model)
-    reducer = trainer.BucketedGradReducer(model) if world > 1 else None
-    step = trainer.TrainStep(model, opt, reducer)
     x, y = synthetic_batch(batch, S, classes, seed=rank, device=device)     # resident in HBM before timing
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph is single-GPU only")
+        opt = trainer.make_optimizer(model, capturable=True)
+        step = trainer.GraphedTrainStep(model, opt, x, y)
+        args.prof_steps = 0                                # events cannot be recorded inside a replayed graph
+    else:
+        opt = trainer.make_optimizer(model)
+        reducer = trainer.BucketedGradReducer(model) if world > 1 else None
+        step = trainer.TrainStep(model, opt, reducer)
 
     def sync():
         if world > 1:
@@ -272,7 +280,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"CALM-ViT {args.workload} cls, {S}x{S}x3 synthetic, bs={batch}/GPU, "
                                    f"{args.precision} matmuls, fwd+loss+bwd+clip+AdamW", "global_batch": world * batch,
-                       "parallelism": f"dp{world}", "loss": float(loss)},
+                       "parallelism": f"dp{world}", "loss": float(loss), "hipgraph": bool(args.graph)},
             "model_tflops": round(value * wl["gflop_img"] / 1e3, 2),
             "roofline": roofline,
         }
