@@ -1,0 +1,93 @@
+"""One training iteration (distributed_trainer_cls.py:79-96: forward, soft-target CE, backward, clip_grad_norm_(1.0),
+AdamW(lr 3.1e-3, wd 0.02, betas (0.9, 0.98)), zero_grad) of the package on the MI355X against the same iteration
+driven through the CPU oracle, and the hipGraph-captured step against the eager one."""
+from importlib import import_module
+
+import numpy as np
+import pytest
+import torch
+
+import calm_vit_dte_amd as calm
+import weights as W
+from helpers import CONFIGS, load_golden, rel_err
+from oracle import calm_oracle as O
+from test_host_logic_cpu import build_model
+
+pytestmark = pytest.mark.gpu
+trainer = import_module("calm_vit_dte_amd.trainer")
+
+
+def _batch(name, bs=4):
+    cfg = CONFIGS[name]
+    g = np.random.default_rng(5)
+    x = torch.from_numpy(g.standard_normal((bs, 3, cfg.seq_length, cfg.seq_length)).astype(np.float32))
+    a, b = g.integers(0, cfg.out_features, bs), g.integers(0, cfg.out_features, bs)
+    y = np.zeros((bs, cfg.out_features), dtype=np.float32)
+    y[np.arange(bs), a] += 0.7
+    y[np.arange(bs), b] += 0.3
+    return cfg, x, torch.from_numpy(y)
+
+
+def test_train_step_matches_oracle_step():
+    name = "tiny32_cls"                                   # no latent noise: the step is deterministic
+    g = load_golden(name)
+    cfg, x, y = _batch(name)
+    # --- CPU oracle step
+    P = {k: torch.from_numpy(v) for k, v in W.make_params(O.vit_param_shapes(cfg), 1234).items()}
+    for k in P:
+        if O.is_buffer(k):
+            P[k] = torch.from_numpy(g["warm/" + k].copy())
+    leaves = {k: P[k].requires_grad_(True) for k in P if not O.is_buffer(k)}
+    before = {k: v.detach().clone() for k, v in leaves.items()}
+    opt_o = torch.optim.AdamW(list(leaves.values()), lr=3.1e-3, weight_decay=0.02, betas=(0.9, 0.98))
+    out, _ = O.vit_forward(P, cfg, x, True)
+    loss_o = torch.nn.functional.cross_entropy(out, y)
+    loss_o.backward()
+    norm_o = torch.nn.utils.clip_grad_norm_(list(leaves.values()), 1.0)
+    grads_o = {k: v.grad.clone() for k, v in leaves.items()}
+    opt_o.step()
+    # --- package step on the GPU
+    m = build_model(name, g, "cuda").train()
+    opt = trainer.make_optimizer(m)
+    step = trainer.TrainStep(m, opt, None)
+    params = dict(m.named_parameters())
+    y_hat, _ = m(x.cuda())
+    loss_h = trainer.soft_target_cross_entropy(y_hat.squeeze(), y.cuda())
+    loss_h.backward()
+    norm_h = torch.nn.utils.clip_grad_norm_(step.params, 1.0)
+    assert abs(float(loss_h) - float(loss_o)) < 1e-4 * max(1.0, abs(float(loss_o)))
+    assert abs(float(norm_h) - float(norm_o)) < 1e-3 * float(norm_o)
+    for k in ("autoencoder.encoder_blocks.0.encoder.q_proj.weight_orig", "head.2.weight_orig",
+              "autoencoder.encoder_blocks.1.cross.linear_mask.0.bias", "autoencoder.ln_final.weight"):
+        assert rel_err(params[k].grad, grads_o[k]) < 1e-3, k
+    opt.step()
+    # AdamW's first update is lr * g/(|g|+eps): compare where the gradient is not vanishing
+    bad = tot = 0
+    for k, p in params.items():
+        sel = grads_o[k].abs() > 1e-6 * grads_o[k].abs().max()
+        d_h = (p.detach().cpu() - before[k])[sel]
+        d_o = (leaves[k].detach() - before[k])[sel]
+        bad += int(((d_h - d_o).abs() > 1e-4 * 3.1e-3 + 1e-7).sum())
+        tot += int(sel.sum())
+    assert bad <= 1e-3 * tot, (bad, tot)
+
+
+def test_graphed_step_equals_eager_step():
+    name = "tiny32_cls"
+    g = load_golden(name)
+    cfg, x, y = _batch(name, bs=8)
+    x, y = x.cuda(), y.cuda()
+    results = []
+    for graphed in (False, True):
+        m = build_model(name, g, "cuda").train()
+        opt = trainer.make_optimizer(m, capturable=True)
+        eager = trainer.TrainStep(m, opt, None)
+        eager(x, y)                                   # step 1 eagerly in both runs (also builds the lazy plans)
+        step = trainer.GraphedTrainStep(m, opt, x, y, warmup=0) if graphed else eager
+        losses = [float(step(x, y)[0]) for _ in range(2)]     # steps 2 and 3: replayed vs eager
+        torch.cuda.synchronize()
+        results.append(({k: v.detach().clone() for k, v in m.state_dict().items()}, losses))
+    (sd_e, l_e), (sd_g, l_g) = results
+    assert abs(l_e[-1] - l_g[-1]) < 1e-4 * max(1.0, abs(l_e[-1])), (l_e, l_g)
+    worst = max(float((sd_e[k] - sd_g[k]).abs().max()) for k in sd_e)
+    assert worst < 5e-4, worst                        # weight gradients use fp32 atomics (order-dependent bits)
