@@ -17,6 +17,10 @@
 // land 16 banks apart (conflict-free); global->LDS staging is register-prefetched one chunk ahead.
 #include "common.h"
 
+#ifndef ATT_TR_ROWFAST
+#define ATT_TR_ROWFAST 1   // W1-chunk staging: hidden rows fastest over lanes (16-way LDS write conflict otherwise)
+#endif
+
 namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -72,9 +76,15 @@ __device__ __forceinline__ void tr_load(Regs<NV>& rg, const float* __restrict__ 
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         const int f = threadIdx.x + u * nt;
+#if ATT_TR_ROWFAST
+        const int r = f & 15, cq = f >> 4;            // 16 rows fastest: LDS writes hit 16 consecutive banks
+        f32x4v val = {0.f, 0.f, 0.f, 0.f};
+        if (cq < per_row) val = *reinterpret_cast<const f32x4v*>(src + (long)r * stride + 4 * cq);
+#else
         const int r = f / per_row, cq = f - r * per_row;
         f32x4v val = {0.f, 0.f, 0.f, 0.f};
         if (r < 16) val = *reinterpret_cast<const f32x4v*>(src + (long)r * stride + 4 * cq);
+#endif
         rg.v[u] = val;
     }
 }
@@ -85,8 +95,13 @@ __device__ __forceinline__ void tr_store(const Regs<NV>& rg, float* __restrict__
 #pragma unroll
     for (int u = 0; u < NV; ++u) {
         const int f = threadIdx.x + u * nt;
+#if ATT_TR_ROWFAST
+        const int r = f & 15, cq = f >> 4;
+        if (cq < per_row) {
+#else
         const int r = f / per_row, cq = f - r * per_row;
         if (r < 16) {
+#endif
 #pragma unroll
             for (int e = 0; e < 4; ++e) dst[(4 * cq + e) * ld + r] = rg.v[u][e];
         }
