@@ -142,29 +142,68 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
             if (col >= p.N) continue;
             const float bj = p.bias ? p.bias[col] : 0.f;
             const float sj = p.col_scale ? p.col_scale[col] : 1.f;
+            const int row0 = m0 + wm * (32 * MT) + 32 * i + 4 * h;
+            if (p.atomic) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = row0 + (e & 3) + 8 * (e >> 2);
+                    if (row < p.M) atomicAdd(Cb + (long)row * p.c_rs + col, acc[i][j][e] * scale);
+                }
+                continue;
+            }
+            // Each extra operand (aux for GELU', residual, old C) is fetched as 16 independent loads into one
+            // temporary (rows past M clamped to row 0) and folded into the accumulator in place, one operand at a
+            // time: loads stay in flight together without holding three 16-register arrays live.
+            float v[16], t[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e] * scale + bj;
+            if (Pb) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = row0 + (e & 3) + 8 * (e >> 2);
+                    if (row < p.M) Pb[(long)row * p.c_rs + col] = v[e];
+                }
+            }
+            if (p.act == CALM_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = gelu_erf_f(v[e]);
+            } else if (p.act == CALM_ACT_GELU_BWD) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = row0 + (e & 3) + 8 * (e >> 2);
+                    t[e] = Xb[(long)(row < p.M ? row : 0) * p.c_rs + col];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] *= gelu_erf_grad_f(t[e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] *= sj;
+            if (Rb) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = row0 + (e & 3) + 8 * (e >> 2);
+                    t[e] = Rb[(long)(row < p.M ? row : 0) * p.r_rs + col];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] += t[e];
+            }
+            if (p.accumulate) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = row0 + (e & 3) + 8 * (e >> 2);
+                    t[e] = Cb[(long)(row < p.M ? row : 0) * p.c_rs + col];
+                }
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] += t[e];
+            }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int row = m0 + wm * (32 * MT) + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (row >= p.M) continue;
-                const long off = (long)row * p.c_rs + col;
-                float v = acc[i][j][e] * scale;
-                if (p.atomic) {
-                    atomicAdd(Cb + off, v);
-                    continue;
-                }
-                v += bj;
-                if (Pb) Pb[off] = v;
-                if (p.act == CALM_ACT_GELU) v = gelu_erf_f(v);
-                else if (p.act == CALM_ACT_GELU_BWD) v *= gelu_erf_grad_f(Xb[off]);
-                v *= sj;
-                if (Rb) v += Rb[(long)row * p.r_rs + col];
-                if (p.accumulate) v += Cb[off];
-                Cb[off] = v;
+                const int row = row0 + (e & 3) + 8 * (e >> 2);
+                if (row < p.M) Cb[(long)row * p.c_rs + col] = v[e];
             }
         }
     }
 }
-
 
 template <bool AKC, bool BKC, int VEC, int BN_>
 __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {

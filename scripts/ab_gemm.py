@@ -39,4 +39,21 @@ D = H * hd
 q, k, P = g(B, S, D), g(B, S, D), g(B, H, S, S)
 t = t_med(lambda: be.gemm(q, k, P, S, S, hd, (D, 1, S * D, hd), (D, 1, S * D, hd), (S, H * S * S, S * S), batch=(B, H)))
 print(f"batched logits 224x224x112 x1536: {t:7.3f} ms {2.0*S*S*hd*B*H/1e9/t:6.1f} TF")
-print(f"sum {tot + t:.3f} ms")
+tot += t
+# epilogue-heavy short-K shapes
+M, N, K = 45056, 352, 176
+dy, w, aux, out = g(M, K), g(K, N), g(M, N), g(M, N)      # dgrad with GELU' epilogue: out = (dy . w) * gelu'(aux)
+t = t_med(lambda: be.gemm(dy, w, out, M, N, K, (K, 1, 0, 0), (1, N, 0, 0), (N, 0, 0), act=2, aux=aux, split_k=1))
+print(f"dgrad+GELU' {M}x{N}x{K}: {t:7.3f} ms {2.0*M*N*K/1e9/t:6.1f} TF"); tot += t
+B2, S2, D2 = 256, 176, 528
+dR, kk, dq = g(B2, S2, S2), g(B2, S2, D2), g(B2, S2, D2)   # dq += dR . K  (accumulate epilogue), per image
+t = t_med(lambda: be.gemm(dR, kk, dq, S2, D2, S2, (S2, 1, S2 * S2, 0), (1, D2, S2 * D2, 0), (D2, S2 * D2, 0), batch=(B2, 1), accumulate=True))
+print(f"accumulate {S2}x{D2}x{S2} x{B2}: {t:7.3f} ms {2.0*S2*D2*S2*B2/1e9/t:6.1f} TF"); tot += t
+mask = g(B, S, S)
+t = t_med(lambda: be.gemm(q, k, P, S, S, hd, (D, 1, S * D, hd), (D, 1, S * D, hd), (S, H * S * S, S * S), batch=(B, H), alpha=0.1, residual=mask, r=(S, S * S, 0)))
+print(f"logits+mask residual 224x224x112 x1536: {t:7.3f} ms {2.0*S*S*hd*B*H/1e9/t:6.1f} TF"); tot += t
+x, w, res, y = g(57344, 672), g(672, 672), g(57344, 672), g(57344, 672)
+ls = g(672)
+t = t_med(lambda: be.gemm(x, w, y, 57344, 672, 672, (672, 1, 0, 0), (672, 1, 0, 0), (672, 0, 0), col_scale=ls, residual=res, r=(672, 0, 0), split_k=1))
+print(f"out_proj (ls+residual) 57344x672x672: {t:7.3f} ms {2.0*57344*672*672/1e9/t:6.1f} TF"); tot += t
+print(f"sum {tot:.3f} ms")
