@@ -14,6 +14,9 @@
 
 namespace {
 
+#ifndef CALM_GEMM_ABLATE
+#define CALM_GEMM_ABLATE 0       // timing experiments only (wrong results): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no LDS reads, 16 every k-tile re-reads tile 0 (cache-hot), 32 A loaded once, 64 no MFMA (one VALU fma per fragment pair)
+#endif
 #ifndef CALM_GEMM_BK
 #define CALM_GEMM_BK 16          // k-tile of the fp32 family (A/B'd: 16 vs 32)
 #endif
@@ -38,6 +41,27 @@ struct GemmP {
     int atomic;     // partial results combined with fp32 atomics (split-K / batch-reduce)
     int tiles_m, tiles_n;
 };
+
+#ifdef CALM_GEMM_STAMP
+// timing experiment build only: per-workgroup phase cycle counts of wave 0 (s_memtime), read back by calm_debug_stamps
+constexpr int STAMP_MAX_WG = 8192, STAMP_N = 12;
+__device__ long long g_stamps[STAMP_MAX_WG * STAMP_N];
+__device__ __forceinline__ long long stamp_now() {
+    long long t;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+__device__ __forceinline__ long long stamp_real() {      // 100 MHz, one counter for the whole device
+    long long t;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory");
+    return t;
+}
+#define STAMP(var) const long long var = stamp_now()
+#define STAMP_REAL(var) const long long var = stamp_real()
+#else
+#define STAMP(var)
+#define STAMP_REAL(var)
+#endif
 
 template <bool KC, int VEC, int ROWS>
 __device__ __forceinline__ void load_operand(const float* __restrict__ base, long rs, long cs, int row0,
@@ -206,7 +230,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
 }
 
 template <bool AKC, bool BKC, int VEC, int BN_>
-__global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
+// min 4 waves/SIMD: keeps the accumulators in arch VGPRs (<=128 registers in total) instead of VGPR+AGPR (152-182),
+// i.e. 4 resident workgroups per CU instead of 3 (BN=96) / 2 (BN=128); A/B'd +3% over the shape mix, +10..15% on
+// short-K and per-head batched shapes
+#ifndef CALM_GEMM_WAVES
+#define CALM_GEMM_WAVES 4
+#endif
+#ifndef CALM_GEMM_BF16_WAVES
+#define CALM_GEMM_BF16_WAVES 3      // bf16-operand family: 3 (A/B: bf16 -4% time; 4 spills; bf16x3 is LDS-limited to 2 either way)
+#endif
+__global__ __launch_bounds__(NTHREADS, CALM_GEMM_WAVES) void gemm_f32_kernel(const GemmP p) {
     constexpr int WN = BN_ == 128 ? 2 : 1;        // wave grid: 2x2 (128x128 tile) or 4x1 (128x96 tile)
     constexpr int MT = BN_ == 128 ? 2 : 1;        // 32x32 MFMA tiles per wave along M
     constexpr int NT = BN_ / (WN * 32);           // ... along N (2 or 3)
@@ -230,6 +263,10 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
     const int kb_begin = z * p.kb_per_z;
     const int kb_end = min(kb_begin + p.kb_per_z, p.kb_total);
     if (kb_begin >= kb_end && p.atomic) return;
+    STAMP_REAL(t_begin);
+#ifdef CALM_GEMM_STAMP
+    long long c_issue = 0, c_mfma = 0, c_vm = 0, c_st = 0, c_bar = 0;
+#endif
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -243,8 +280,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
 
     auto fetch = [&](int kb) {
         const int b = kb / p.kpb;
+#if (CALM_GEMM_ABLATE & 16)
+        const int k0 = 0;
+#else
         const int k0 = (kb - b * p.kpb) * BK;
+#endif
         const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
+#if (CALM_GEMM_ABLATE & 32)
+        if (kb == kb_begin)
+#endif
         load_operand<AKC, VEC, BM>(p.A + b0 * p.a_b0 + b1 * p.a_b1, p.a_rs, p.a_cs, m0, p.M, k0, p.K, ra);
         load_operand<BKC, VEC, BN_>(p.B + b0 * p.b_b0 + b1 * p.b_b1, p.b_rs, p.b_cs, n0, p.N, k0, p.K, rb);
     };
@@ -256,33 +300,79 @@ __global__ __launch_bounds__(NTHREADS) void gemm_f32_kernel(const GemmP p) {
         store_operand<BKC, VEC>(Bs[0], rb);
     }
     __syncthreads();
+    STAMP_REAL(t_loop);
+    STAMP(m_loop);
 
     for (int kb = kb_begin; kb < kb_end; ++kb) {
         const bool more = kb + 1 < kb_end;
+        STAMP(s0);
+#if !(CALM_GEMM_ABLATE & 1)
         if (more) fetch(kb + 1);
+#endif
+        STAMP(s1);
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             const int kk = 2 * s + h;
             float af[MT], bf[NT];
+#if (CALM_GEMM_ABLATE & 8)
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = ra[(s + i) % NREG];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = rb[(s + j) % NREG];
+#else
 #pragma unroll
             for (int i = 0; i < MT; ++i) af[i] = As[buf][kk][wm * (32 * MT) + 32 * i + r];
 #pragma unroll
             for (int j = 0; j < NT; ++j) bf[j] = Bs[buf][kk][wn * (32 * NT) + 32 * j + r];
+#endif
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
+#if (CALM_GEMM_ABLATE & 64)
+                    acc[i][j][s] += af[i] * bf[j];
+#else
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+#endif
         }
+        STAMP(s2);
+#ifdef CALM_GEMM_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        STAMP(s3);
+#if !(CALM_GEMM_ABLATE & 2)
         if (more) {
             store_operand<AKC, VEC>(As[buf ^ 1], ra);
             store_operand<BKC, VEC>(Bs[buf ^ 1], rb);
         }
+#endif
+        STAMP(s4);
+#if !(CALM_GEMM_ABLATE & 4)
         __syncthreads();
+#endif
+        STAMP(s5);
+#ifdef CALM_GEMM_STAMP
+        c_issue += s1 - s0; c_mfma += s2 - s1; c_vm += s3 - s2; c_st += s4 - s3; c_bar += s5 - s4;
+#endif
         buf ^= 1;
     }
+    STAMP(m_epi);
+    STAMP_REAL(t_epi);
 
     gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z);
+#ifdef CALM_GEMM_STAMP
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP_REAL(t_end);
+    const int wg = blockIdx.x + gridDim.x * blockIdx.y;
+    if (tid == 0 && wg < STAMP_MAX_WG) {
+        long long* o = g_stamps + (long)wg * STAMP_N;
+        o[0] = t_begin; o[1] = t_loop; o[2] = t_epi; o[3] = t_end;
+        o[4] = c_issue; o[5] = c_mfma; o[6] = c_vm; o[7] = c_st; o[8] = c_bar;
+        o[9] = __builtin_amdgcn_s_getreg(4 | (31 << 11));       // HW_ID
+        o[10] = __builtin_amdgcn_s_getreg(20 | (31 << 11));     // XCC_ID
+        o[11] = m_epi - m_loop;
+    }
+#endif
 }
 
 
@@ -377,7 +467,7 @@ __device__ __forceinline__ bf16x8 c_frag(const __bf16* __restrict__ plane, int r
 }
 
 template <bool AKC, bool BKC, int NPASS, int BN_>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16c_kernel(const GemmP p) {
+__global__ __launch_bounds__(NTHREADS, CALM_GEMM_BF16_WAVES) void gemm_bf16c_kernel(const GemmP p) {
     constexpr int WN = BN_ == 128 ? 2 : 1;
     constexpr int MT = BN_ == 128 ? 2 : 1;
     constexpr int NT = BN_ / (WN * 32);
@@ -490,6 +580,12 @@ int launch(const GemmP& p, dim3 grid, int bn, hipStream_t s) {
 inline bool mult4(int64_t x) { return (x & 3) == 0; }
 
 }  // namespace
+
+#ifdef CALM_GEMM_STAMP
+extern "C" int calm_debug_stamps(long long* host, int n_wg) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(long long) * STAMP_N * n_wg, 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     if (!a || !a->A || !a->B || !a->C) return CALM_E_INVAL;
