@@ -608,13 +608,6 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     p.residual = (const float*)a->residual; p.r_rs = a->r_rs; p.r_b0 = a->r_b0; p.r_b1 = a->r_b1;
     p.C_pre = (float*)a->C_pre; p.aux = (const float*)a->aux;
     p.act = a->act; p.accumulate = a->accumulate;
-    // N tile: 128 (2x2 waves) or 96 (4x1 waves), whichever pads N less (672, 528, 1344, 1056, 480 ... are
-    // multiples of 96 or nearly so; ties go to 128 for the better A-panel reuse)
-    const int pad128 = (a->N + 127) / 128 * 128, pad96 = (a->N + 95) / 96 * 96;
-    const int bn = pad96 < pad128 ? 96 : 128;
-    p.tiles_m = (a->M + BM - 1) / BM;
-    p.tiles_n = (a->N + bn - 1) / bn;
-    const int tiles = p.tiles_m * p.tiles_n;
     const int batch = a->batch0 * a->batch1;
     const bool akc = a->a_cs == 1;
     const bool bkc = a->b_cs == 1;
@@ -626,8 +619,28 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     const int family = vec ? a->dtype : CALM_F32;
     const int bk = family == CALM_F32 ? BK : CK;
     p.kpb = (a->K + bk - 1) / bk;
-
     const bool trivial_epi = !a->bias && !a->col_scale && !a->residual && !a->C_pre && a->act == CALM_ACT_NONE;
+
+    // N tile: 128 (2x2 waves) or 96 (4x1 waves).  k-split launches (work spread evenly whatever the tile count) take
+    // the width that pads N less (672, 528, 1344, 1056, 480 ... are multiples of 96 or nearly so), ties to 128 for
+    // the better A-panel reuse.  Data-parallel launches take the width with the lower estimated time: the
+    // workgroups resident on a CU share its matrix pipe, so a launch lasts about ceil(work items / CUs) x width
+    // (A/B over the model's shapes: N=240 and N=352 are 12-20% faster on 96 although 128 pads less).
+    p.tiles_m = (a->M + BM - 1) / BM;
+    const int pad128 = (a->N + 127) / 128 * 128, pad96 = (a->N + 95) / 96 * 96;
+    int bn = pad96 < pad128 ? 96 : 128;
+    const bool k_split = a->reduce_batch || a->split_k > 1 ||
+                         (a->split_k == 0 && batch == 1 && trivial_epi && p.tiles_m * ((a->N + bn - 1) / bn) < 256 &&
+                          p.kpb >= 64);
+    if (!k_split) {
+        const long cus = 256;
+        const long items96 = (long)p.tiles_m * (pad96 / 96) * batch, items128 = (long)p.tiles_m * (pad128 / 128) * batch;
+        const long cost96 = (items96 + cus - 1) / cus * 96, cost128 = (items128 + cus - 1) / cus * 128;
+        bn = cost96 < cost128 ? 96 : 128;
+    }
+    p.tiles_n = (a->N + bn - 1) / bn;
+    const int tiles = p.tiles_m * p.tiles_n;
+
     int nsplit = 1;
     p.atomic = 0;
     if (a->reduce_batch) {
@@ -637,7 +650,7 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
         const int max_split = (p.kb_total + 7) / 8;
         if (nsplit > max_split) nsplit = max_split;
         if (nsplit < 1) nsplit = 1;
-    } else if (a->split_k > 1 || (a->split_k == 0 && batch == 1 && trivial_epi && tiles < 256 && p.kpb >= 64)) {
+    } else if (k_split) {
         if (batch != 1) return CALM_E_UNSUPP;
         nsplit = a->split_k > 1 ? a->split_k : 768 / tiles;
         const int max_split = (p.kpb + 15) / 16;
