@@ -37,6 +37,19 @@ def get_matmul_precision():
     return _precision
 
 
+def effective_precision():
+    """The pipe a GEMM issued now runs on.  Inside `torch.autocast("cuda", dtype=torch.bfloat16)` — how the reference
+    trainer calls the model (distributed_trainer_cls.py:84-85) — Linear/matmul operands are rounded to bf16 with fp32
+    accumulation, i.e. the 'bf16' mode; activations and parameters stay fp32 tensors.  Outside autocast: the mode
+    chosen with set_matmul_precision."""
+    if torch.is_autocast_enabled("cuda"):
+        dt = torch.get_autocast_dtype("cuda")
+        if dt != torch.bfloat16:
+            raise NotImplementedError(f"autocast dtype {dt} is not supported on this path (the reference uses bfloat16)")
+        return "bf16"
+    return _precision
+
+
 def _ptr(t, allow_none=False):
     if t is None:
         if allow_none:
@@ -93,7 +106,7 @@ class HipBackend:
         g.accumulate = int(accumulate)
         g.reduce_batch = int(reduce_batch)
         g.split_k = split_k
-        g.dtype = PRECISIONS[_precision]
+        g.dtype = PRECISIONS[effective_precision()]
         _lib.check(self.lib.calm_gemm(C.byref(g), _stream()), "calm_gemm")
 
     # ---- LayerNorm --------------------------------------------------------------------

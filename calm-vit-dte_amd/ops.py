@@ -14,6 +14,13 @@ from torch.autograd.function import once_differentiable
 
 from .backend import ACT_GELU, ACT_GELU_BWD, ACT_NONE, get_backend
 
+# The reference calls the model under autocast(bfloat16) (distributed_trainer_cls.py:84): custom_fwd records the
+# autocast state of the forward call, custom_bwd re-establishes it around backward (autograd runs backward outside the
+# `with` block), and backend.effective_precision() maps that state to the GEMM pipe — forward and backward GEMMs of
+# one call therefore always use the same arithmetic.
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda")
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+
 _noise_override = None
 
 
@@ -77,6 +84,7 @@ class LayerNormFn(Function):
     """LayerNorm(D, eps=1e-6, bias=False) (Vi_Tools:131-132,197,494)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w, eps):
         be = get_backend()
         x = _c(x)
@@ -91,6 +99,7 @@ class LayerNormFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dy):
         be = get_backend()
         x, w, mean, rstd = ctx.saved_tensors
@@ -107,6 +116,7 @@ class SNLinearFn(Function):
     epilogues the block applies right after it (Vi_Tools:265-267, 276-277, 230-231, 300, 308)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w, bias, ls, residual, u, v, sigma, act):
         be = get_backend()
         x = _c(x)
@@ -127,6 +137,7 @@ class SNLinearFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dy):
         be = get_backend()
         x2, w, ls, u, v, sigma, pre = ctx.saved_tensors
@@ -160,6 +171,7 @@ class MlpFn(Function):
     CALM_ViT_V2.py:49-53,76 cls head).  The GELU backward is fused into the dgrad GEMM epilogue."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w1, b1, w2, b2, ls, residual, u1, v1, s1, u2, v2, s2):
         be = get_backend()
         x = _c(x)
@@ -181,6 +193,7 @@ class MlpFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dout):
         be = get_backend()
         x2, hp, hg, w1, w2, ls, u1, v1, s1, u2, v2, s2 = ctx.saved_tensors
@@ -216,6 +229,7 @@ class SeqLinearFn(Function):
     (Vi_Tools:224-229,250-264,304-306) as a batched GEMM with a transposed operand (no copies)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w, u, v, sigma):
         be = get_backend()
         x = _c(x)
@@ -228,6 +242,7 @@ class SeqLinearFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dy):
         be = get_backend()
         x, w, u, v, sigma = ctx.saved_tensors
@@ -251,6 +266,7 @@ class RopeFn(Function):
     """out[...,h,:dc] = content, out[...,h,dc:] = rope(xr) with learned inv_freq (Vi_Tools:80-95,275-285)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, content, xr, inv_freq, H):
         be = get_backend()
         xr = _c(xr)
@@ -269,6 +285,7 @@ class RopeFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dout):
         be = get_backend()
         xr, table = ctx.saved_tensors
@@ -286,6 +303,7 @@ class LatentMaskAttentionFn(Function):
     along the key axis and shared by all heads (Vi_Tools:288-299).  q:[B,Sq,H*hd] k,v:[B,Skv,H*hd]."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, q, k, v, w1, b1, w2, b2, u1, v1, s1, u2, v2, s2, H):
         be = get_backend()
         q, k, v = _c(q), _c(k), _c(v)
@@ -321,6 +339,7 @@ class LatentMaskAttentionFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dout):
         be = get_backend()
         q, k, v, R, hp, hg, P, w1, w2, u1, v1, s1, u2, v2, s2 = ctx.saved_tensors
@@ -376,6 +395,7 @@ class LatentFn(Function):
     tensor's KL term -0.5*mean(1 + 2 log std - mean^2 - std^2) (Vi_Tools:24-25)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, mv, noise):
         be = get_backend()
         mv = _c(mv)
@@ -395,6 +415,7 @@ class LatentFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dz, _dstd, dkl):
         be = get_backend()
         mv, noise, std = ctx.saved_tensors
@@ -411,6 +432,7 @@ class AddFn(Function):
     """Residual / U-net skip adds (Vi_Tools:309,315,403,513-522) and the latent running sum (43-44)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, a, b):
         be = get_backend()
         a, b = _c(a), _c(b)
@@ -427,6 +449,7 @@ class ImageToRowsFn(Function):
     """[B,3,S,S] -> [B,S,3S] (Vi_Tools:389-391)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, img):
         be = get_backend()
         img = _c(img)
@@ -439,6 +462,7 @@ class ImageToRowsFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, g):
         be = get_backend()
         B, S = ctx.dims
@@ -452,6 +476,7 @@ class GridTransposeFn(Function):
     """rows <-> columns of the [B,S,S,3] token grid (Vi_Tools:394-395,397-398); self-inverse."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x):
         be = get_backend()
         x = _c(x)
@@ -463,6 +488,7 @@ class GridTransposeFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, g):
         be = get_backend()
         g = _c(g)
@@ -476,6 +502,7 @@ class MeanSeqFn(Function):
     """AdaptiveAvgPool1d(1) over the sequence (CALM_ViT_V2.py:74-75)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x):
         be = get_backend()
         x = _c(x)
@@ -487,6 +514,7 @@ class MeanSeqFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, g):
         be = get_backend()
         B, S, D = ctx.dims
@@ -502,6 +530,7 @@ class CnnResidualFn(Function):
     maps kept in LDS and recomputed in backward (only x is saved)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, w0, b0, w2, b2, w4, b4, u0, v0, s0, u2, v2, s2, u4, v4, s4):
         be = get_backend()
         x = _c(x)
@@ -515,6 +544,7 @@ class CnnResidualFn(Function):
 
     @staticmethod
     @once_differentiable
+    @_amp_bwd
     def backward(ctx, dy):
         be = get_backend()
         x, w0, b0, w2, b2, w4, b4, u0, v0, s0, u2, v2, s2, u4, v4, s4 = ctx.saved_tensors

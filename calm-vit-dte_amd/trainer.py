@@ -166,15 +166,18 @@ def soft_target_cross_entropy(logits, soft_targets):
 class TrainStep:
     """One iteration of distributed_trainer_cls.py:79-96 (per rank)."""
 
-    def __init__(self, model, optimizer, reducer=None, max_norm=1.0, scaler=None):
+    def __init__(self, model, optimizer, reducer=None, max_norm=1.0, scaler=None, autocast_dtype=None):
         self.model, self.opt, self.reducer = model, optimizer, reducer
         self.max_norm = max_norm
         self.scaler = scaler
+        self.autocast_dtype = autocast_dtype          # torch.bfloat16: the reference's `with autocast(...)` (cls:84)
         self.params = [p for p in model.parameters() if p.requires_grad]
 
     def __call__(self, x, y_soft):
-        y_hat, _ = self.model(x)                                           # cls:85
-        loss = soft_target_cross_entropy(y_hat.squeeze(), y_soft)          # cls:86
+        with torch.autocast(device_type="cuda", dtype=self.autocast_dtype or torch.bfloat16,
+                            enabled=self.autocast_dtype is not None and x.is_cuda):        # cls:84
+            y_hat, _ = self.model(x)                                       # cls:85
+            loss = soft_target_cross_entropy(y_hat.squeeze(), y_soft)      # cls:86
         if self.scaler is not None:
             self.scaler.scale(loss).backward()                             # cls:87
         else:

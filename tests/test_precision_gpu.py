@@ -112,3 +112,88 @@ def test_small224_block_bf16x3_vs_oracle():
     from test_model_gpu import _block_vs_oracle
     calm.backend.set_matmul_precision("bf16x3")
     _block_vs_oracle(6, 672, 672, 120, 224, 40, 224, False)
+
+
+def test_autocast_bfloat16_is_the_bf16_mode_forward_and_backward():
+    """`with autocast(device_type="cuda", dtype=bfloat16): y_hat, _ = model(x)` (distributed_trainer_cls.py:84-85) must
+    run the same arithmetic as set_matmul_precision('bf16') — in forward AND in backward, which autograd runs after
+    the `with` block has been left — and hand back fp32 tensors.  eval(): bit-identical (no power iteration); train():
+    the batched power iteration sums with fp32 atomics, so sigma moves in its last bit from run to run and the bf16
+    operand rounding amplifies that to ~1e-3 — compared against the distance to the fp32 arithmetic instead."""
+    name = "nano48_cls"
+    g = load_golden(name)
+    cfg = CONFIGS[name]
+    x = torch.from_numpy(W.make_input((2, 3, cfg.seq_length, cfg.seq_length), 2)).cuda()
+    gy = torch.from_numpy(W.make_input((2, cfg.out_features), 3, "gy")).cuda()
+    sd = {k: v.clone() for k, v in build_model(name, g, "cuda").state_dict().items()}
+
+    def fresh():
+        m = build_model(name, g, "cuda").train()
+        m.load_state_dict(sd)
+        return m
+
+    # eval: deterministic
+    m = fresh().eval()
+    with torch.no_grad():
+        calm.backend.set_matmul_precision("bf16")
+        y_mode = m(x)[0]
+        calm.backend.set_matmul_precision("fp32")
+        y_fp32 = m(x)[0]
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            y_auto = m(x)[0]
+            assert calm.backend.effective_precision() == "bf16"
+        assert calm.backend.effective_precision() == "fp32"
+    assert y_auto.dtype == torch.float32
+    assert torch.equal(y_auto, y_mode) and not torch.equal(y_auto, y_fp32)
+
+    # backward of one spectral-normed Linear: autograd runs it outside the `with` block, it must still use the pipe of
+    # its forward (dgrad is launched unsplit: bit-identical; the weight gradient sums k-slices with fp32 atomics)
+    def lin(mode):
+        xx = rnd(512, 96, seed=1).cuda().requires_grad_(True)
+        w = (rnd(144, 96, seed=2) / 10).cuda().requires_grad_(True)
+        u, v, sigma = rnd(144, seed=3).cuda(), rnd(96, seed=4).cuda(), torch.tensor([1.3], device="cuda")
+        args = (xx, w, None, None, None, u, v, sigma, calm.backend.ACT_NONE)
+        if mode == "autocast":
+            with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+                out = calm.ops.SNLinearFn.apply(*args)
+        else:
+            calm.backend.set_matmul_precision(mode)
+            out = calm.ops.SNLinearFn.apply(*args)
+        out.backward(rnd(512, 144, seed=5).cuda())         # outside the context, as in the reference (cls:87)
+        calm.backend.set_matmul_precision("fp32")
+        return out.detach(), xx.grad, w.grad
+
+    o_a, dx_a, dw_a = lin("autocast")
+    o_m, dx_m, dw_m = lin("bf16")
+    o_f, dx_f, dw_f = lin("fp32")
+    assert torch.equal(o_a, o_m) and torch.equal(dx_a, dx_m) and rel_err(dw_a, dw_m) < 1e-5
+    assert rel_err(dx_a, dx_f) > 1e-4 and rel_err(dw_a, dw_f) > 1e-4
+
+
+def test_reference_amp_step_with_grad_scaler():
+    """cls:84-96: autocast forward, GradScaler.scale(loss).backward(), unscale_, clip_grad_norm_, scaler.step/update."""
+    from importlib import import_module
+    trainer = import_module("calm_vit_dte_amd.trainer")
+    name = "nano48_cls"
+    g = load_golden(name)
+    cfg = CONFIGS[name]
+    m = build_model(name, g, "cuda").train()
+    opt = trainer.make_optimizer(m, lr=1e-3)
+    scaler = torch.amp.GradScaler("cuda")
+    x = torch.from_numpy(W.make_input((4, 3, cfg.seq_length, cfg.seq_length), 2)).cuda()
+    y = torch.zeros(4, cfg.out_features, device="cuda")
+    y[torch.arange(4), torch.arange(4) % cfg.out_features] = 1.0
+    losses = []
+    torch.manual_seed(0)
+    for _ in range(6):
+        with torch.autocast(device_type="cuda", dtype=torch.bfloat16):
+            y_hat, _ = m(x)
+            loss = trainer.soft_target_cross_entropy(y_hat.squeeze(), y)
+        scaler.scale(loss).backward()
+        scaler.unscale_(opt)
+        torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1.0, error_if_nonfinite=False)
+        scaler.step(opt)
+        scaler.update()
+        opt.zero_grad()
+        losses.append(float(loss.detach()))
+    assert all(l == l for l in losses) and losses[-1] < losses[0], losses
