@@ -106,7 +106,7 @@ def test_gemm_head_strided_batches(hip, emu):
     assert rel_err(P_hip, ref) < TOL
 
 
-@pytest.mark.parametrize("M,N,K", [(96, 80, 5000), (672, 672, 4096), (3, 32, 9000)])
+@pytest.mark.parametrize("M,N,K", [(96, 80, 5000), (672, 672, 4096), (3, 32, 9000), (240, 480, 20480), (528, 1056, 6000)])
 def test_gemm_split_k_weight_gradient(hip, emu, M, N, K):
     """G = dY^T X with a long reduction: split-K partials combined with fp32 atomics."""
     dy, x = rnd(K, M, seed=1), rnd(K, N, seed=2)
@@ -116,6 +116,20 @@ def test_gemm_split_k_weight_gradient(hip, emu, M, N, K):
     emu.gemm(dy, x, G_ref, *args)
     hip.gemm(dy.cuda(), x.cuda(), G_hip, *args)
     assert rel_err(G_hip, G_ref) < TOL
+
+
+@pytest.mark.parametrize("akc,bkc", [(True, True), (True, False), (False, True), (False, False)])
+@pytest.mark.parametrize("M,N,K", [(160, 100, 512), (528, 96, 1028), (90, 52, 300)])
+def test_gemm_split_k_all_layouts(hip, emu, M, N, K, akc, bkc):
+    """Explicit split-K (fp32 atomics) over every operand layout, 16-byte and scalar staging (K=300 / M=90 are not
+    multiples of 4 on the strided side)."""
+    A, a = _operand(M, K, (1, 1), akc, 1)
+    B, b = _operand(N, K, (1, 1), bkc, 2)
+    c = (N, 0, 0)
+    C_ref, C_hip = torch.zeros(M, N), torch.full((M, N), 3.0).cuda()
+    emu.gemm(A, B, C_ref, M, N, K, a, b, c, split_k=4)
+    hip.gemm(A.cuda(), B.cuda(), C_hip, M, N, K, a, b, c, split_k=4)
+    assert rel_err(C_hip, C_ref) < TOL
 
 
 def test_gemm_reduce_batch(hip, emu):
