@@ -168,6 +168,7 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
         }
         __syncthreads();
         // h1 on the 20x20 region
+#pragma unroll 2
         for (int p = g; p < H2 * H2; p += BG) {
             const int yy = y0 - 2 + p / H2, xx = x0 - 2 + p % H2;
             const bool in = yy >= 0 && yy < S && xx >= 0 && xx < S;
@@ -176,6 +177,7 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
         }
         __syncthreads();
         // dL/dh2p on the 18x18 region (+ weight grads of conv4 / dwconv on the tile's own pixels)
+#pragma unroll 2
         for (int r = g; r < H1 * H1; r += BG) {
             const int ry = r / H1, rx = r % H1;
             const int yy = y0 - 1 + ry, xx = x0 - 1 + rx;
@@ -204,6 +206,7 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
         }
         __syncthreads();                                   // d2s complete, h1s no longer read
         // dL/dh1p on the tile; staged over the h1 image for the channel reduction of conv0^T
+#pragma unroll 2
         for (int q = g; q < T * T; q += BG) {
             const int qy = q / T, qx = q % T;
             const int yy = y0 + qy, xx = x0 + qx;
