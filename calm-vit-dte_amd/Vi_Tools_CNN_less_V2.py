@@ -221,6 +221,21 @@ class VMLA_Block(torch.nn.Module):
         with sn_scope(self):
             return self._forward(input_q, input_kv, state_manager)
 
+    def _project_qkv(self, qz, kz, vz):
+        """q_proj / k_proj / v_proj (Vi_Tools:265-267).  Projections that read the SAME tensor — all three in a plain
+        self-attention block, k and v whenever the key and value inputs coincide — run as one grouped launch."""
+        pq, pk, pv = self.q_proj, self.k_proj, self.v_proj
+        pack = lambda *ps: [t for p_ in ps for t in (p_.weight_orig, p_.weight_u, p_.weight_v, p_.sigma())]
+        same_shape = pq.weight_orig.shape == pk.weight_orig.shape == pv.weight_orig.shape
+        if any(p_.bias is not None for p_ in (pq, pk, pv)) or not same_shape or not ops.GROUP_PROJECTIONS:
+            return pq(qz), pk(kz), pv(vz)
+        if qz is kz and kz is vz:
+            return ops.SNLinearGroupFn.apply(qz, *pack(pq, pk, pv))
+        if kz is vz:
+            k, v = ops.SNLinearGroupFn.apply(kz, *pack(pk, pv))
+            return pq(qz), k, v
+        return pq(qz), pk(kz), pv(vz)
+
     def _forward(self, input_q, input_kv, state_manager):
         H = self.heads
         residual = input_q
@@ -250,9 +265,7 @@ class VMLA_Block(torch.nn.Module):
                 vz = self._seq(self.t_vz_upsample, vz)
                 qr = self._seq(self.t_qr_proj, qr)
                 kr = self._seq(self.t_kr_proj, kr)
-        qz = self.q_proj(qz)                                             # 265-267
-        kz = self.k_proj(kz)
-        v = self.v_proj(vz)
+        qz, kz, v = self._project_qkv(qz, kz, vz)                        # 265-267
         if self.reduce:                                                  # 275-281 decoupled RoPE
             qr = self.qr_proj(qr)
             kr = self.kr_proj(kr)

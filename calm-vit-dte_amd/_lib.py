@@ -33,6 +33,8 @@ class GemmArgs(C.Structure):
         ("residual", _p), ("r_rs", _i64), ("r_b0", _i64), ("r_b1", _i64),
         ("C_pre", _p), ("aux", _p),
         ("act", _i32), ("accumulate", _i32), ("reduce_batch", _i32), ("split_k", _i32), ("dtype", _i32),
+        ("n_group", _i32),
+        ("A_group", _p * 4), ("B_group", _p * 4), ("C_group", _p * 4), ("inv_scale_group", _p * 4),
     ]
 
 
@@ -99,7 +101,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.calm_abi_version() != 1:
+    if lib.calm_abi_version() != 2:
         raise RuntimeError("libcalmvit_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -88,6 +88,20 @@ class HipBackend:
              col_scale=None, residual=None, r=(0, 0, 0), C_pre=None, aux=None, act=ACT_NONE,
              accumulate=False, reduce_batch=False, split_k=0):
         g = _lib.GemmArgs()
+        # grouped form: A / B / Cout / inv_scale given as lists of separately allocated tensors, one per b0 entry
+        groups = [len(t) for t in (A, B, Cout, inv_scale) if isinstance(t, (list, tuple))]
+        if groups:
+            n = groups[0]
+            if any(k != n for k in groups) or batch != (n, 1):
+                raise ValueError("grouped gemm: every list needs batch[0] entries and batch[1] must be 1")
+            g.n_group = n
+            for name, t in (("A_group", A), ("B_group", B), ("C_group", Cout), ("inv_scale_group", inv_scale)):
+                if isinstance(t, (list, tuple)):
+                    tab = getattr(g, name)
+                    for i, ti in enumerate(t):
+                        tab[i] = _ptr(ti, True)
+            A, B, Cout = (t[0] if isinstance(t, (list, tuple)) else t for t in (A, B, Cout))
+            inv_scale = None
         g.A, g.B, g.C = _ptr(A), _ptr(B), _ptr(Cout)
         g.M, g.N, g.K = M, N, K
         g.batch0, g.batch1 = batch

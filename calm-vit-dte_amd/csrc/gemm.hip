@@ -40,7 +40,29 @@ struct GemmP {
     int kb_per_z;   // k-blocks per grid.y slice
     int atomic;     // partial results combined with fp32 atomics (split-K / batch-reduce)
     int tiles_m, tiles_n;
+    // grouped form: the b0 entries are separate allocations with their own spectral-norm scale
+    int n_group, reduce_group;     // reduce_group: the groups are summed into one C
+    const float* Ag[4]; const float* Bg[4]; float* Cg[4]; const float* Sg[4];
 };
+
+// operand base of batch entry (b0, b1)
+__device__ __forceinline__ const float* operand_base(const float* base, const float* const (&tab)[4], int n_group,
+                                                     long s0, long s1, int b0, int b1) {
+    if (n_group && tab[0]) return tab[b0] + b1 * s1;
+    return base + b0 * s0 + b1 * s1;
+}
+__device__ __forceinline__ float group_sigma(const GemmP& p, int g) { return p.Sg[g] ? p.Sg[g][0] : 1.f; }
+
+// grouped reduction (C = sum_g A_g B_g^T / sigma_g): the accumulators are kept in units of the CURRENT group's sigma
+// — on entering group g they are multiplied by sigma_g / sigma_{g-1} — and the epilogue divides by the last one.
+template <int MT, int NT>
+__device__ __forceinline__ void group_rescale(const GemmP& p, f32x16 (&acc)[MT][NT], int g) {
+    const float ratio = group_sigma(p, g) / group_sigma(p, g - 1);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] *= ratio;
+}
 
 #ifdef CALM_GEMM_STAMP
 // timing experiment build only: per-workgroup phase cycle counts of wave 0 (s_memtime), read back by calm_debug_stamps
@@ -147,13 +169,18 @@ __device__ __forceinline__ void store_operand(float (*T)[LDT], const float (&reg
 // scale, bias, optional pre-activation store, GELU / GELU', LayerScale, residual, accumulate or atomics.
 template <int MT, int NT>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][NT], int m0, int n0, int wm, int wn,
-                                              int r, int h, int z) {
+                                              int r, int h, int z, int sgroup) {
     float scale = p.alpha;
     if (p.inv_scale) scale = scale / p.inv_scale[0];
     const int zc = p.atomic ? 0 : z;
     const int cb0 = zc / p.batch1, cb1 = zc - cb0 * p.batch1;
     const long coff = cb0 * p.c_b0 + cb1 * p.c_b1;
     float* __restrict__ Cb = p.C + coff;
+    if (p.n_group) {
+        // independent groups: group cb0's sigma and output; grouped reduction: `sgroup` = last group of this k-range
+        scale = scale / group_sigma(p, p.reduce_group ? sgroup : cb0);
+        if (!p.reduce_group && p.Cg[0]) Cb = p.Cg[cb0] + cb1 * p.c_b1;
+    }
     float* __restrict__ Pb = p.C_pre ? p.C_pre + coff : nullptr;
     const float* __restrict__ Xb = p.aux ? p.aux + coff : nullptr;
     const float* __restrict__ Rb = p.residual ? p.residual + cb0 * p.r_b0 + cb1 * p.r_b1 : nullptr;
@@ -289,8 +316,10 @@ __global__ __launch_bounds__(NTHREADS, CALM_GEMM_WAVES) void gemm_f32_kernel(con
 #if (CALM_GEMM_ABLATE & 32)
         if (kb == kb_begin)
 #endif
-        load_operand<AKC, VEC, BM>(p.A + b0 * p.a_b0 + b1 * p.a_b1, p.a_rs, p.a_cs, m0, p.M, k0, p.K, ra);
-        load_operand<BKC, VEC, BN_>(p.B + b0 * p.b_b0 + b1 * p.b_b1, p.b_rs, p.b_cs, n0, p.N, k0, p.K, rb);
+        load_operand<AKC, VEC, BM>(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0,
+                                   p.M, k0, p.K, ra);
+        load_operand<BKC, VEC, BN_>(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0,
+                                    p.N, k0, p.K, rb);
     };
 
     int buf = 0;
@@ -305,6 +334,7 @@ __global__ __launch_bounds__(NTHREADS, CALM_GEMM_WAVES) void gemm_f32_kernel(con
 
     for (int kb = kb_begin; kb < kb_end; ++kb) {
         const bool more = kb + 1 < kb_end;
+        if (p.reduce_group && kb != kb_begin && kb % p.kpb == 0) group_rescale<MT, NT>(p, acc, kb / p.kpb);
         STAMP(s0);
 #if !(CALM_GEMM_ABLATE & 1)
         if (more) fetch(kb + 1);
@@ -359,7 +389,7 @@ __global__ __launch_bounds__(NTHREADS, CALM_GEMM_WAVES) void gemm_f32_kernel(con
     STAMP(m_epi);
     STAMP_REAL(t_epi);
 
-    gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z);
+    gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
 #ifdef CALM_GEMM_STAMP
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     STAMP_REAL(t_end);
@@ -504,8 +534,8 @@ __global__ __launch_bounds__(NTHREADS, CALM_GEMM_BF16_WAVES) void gemm_bf16c_ker
         const int b = kb / p.kpb;
         const int k0 = (kb - b * p.kpb) * CK;
         const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
-        c_load<AKC, BM>(p.A + b0 * p.a_b0 + b1 * p.a_b1, p.a_rs, p.a_cs, m0, p.M, k0, p.K, ra);
-        c_load<BKC, BN_>(p.B + b0 * p.b_b0 + b1 * p.b_b1, p.b_rs, p.b_cs, n0, p.N, k0, p.K, rb);
+        c_load<AKC, BM>(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, k0, p.K, ra);
+        c_load<BKC, BN_>(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0, p.K, rb);
     };
     auto stash = [&](int st) {
         c_store<AKC, NPASS>(lds[st][0][0], lds[st][0][NPL - 1], ra);
@@ -521,6 +551,7 @@ __global__ __launch_bounds__(NTHREADS, CALM_GEMM_BF16_WAVES) void gemm_bf16c_ker
 
     for (int kb = kb_begin; kb < kb_end; ++kb) {
         const bool more = kb + 1 < kb_end;
+        if (p.reduce_group && kb != kb_begin && kb % p.kpb == 0) group_rescale<MT, NT>(p, acc, kb / p.kpb);
         if (more) fetch(kb + 1);
 #pragma unroll
         for (int s = 0; s < CK / 16; ++s) {
@@ -550,7 +581,7 @@ __global__ __launch_bounds__(NTHREADS, CALM_GEMM_BF16_WAVES) void gemm_bf16c_ker
         __syncthreads();
         buf ^= 1;
     }
-    gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z);
+    gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
 }
 
 template <bool AKC, bool BKC, int NPASS>
@@ -595,6 +626,15 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     if (a->b_rs != 1 && a->b_cs != 1) return CALM_E_LAYOUT;
     if (a->act == CALM_ACT_GELU_BWD && !a->aux) return CALM_E_INVAL;
     if (a->act < 0 || a->act > CALM_ACT_GELU_BWD) return CALM_E_INVAL;
+    if (a->n_group < 0 || a->n_group > CALM_GEMM_MAX_GROUP) return CALM_E_INVAL;
+    if (a->n_group) {
+        if (a->batch0 != a->n_group || a->batch1 != 1) return CALM_E_INVAL;
+        if (a->C_pre || a->aux || a->residual || a->inv_scale) return CALM_E_UNSUPP;
+        for (int g = 0; g < a->n_group; ++g) {
+            if ((a->A_group[0] && !a->A_group[g]) || (a->B_group[0] && !a->B_group[g])) return CALM_E_INVAL;
+            if (!a->reduce_batch && a->C_group[0] && !a->C_group[g]) return CALM_E_INVAL;
+        }
+    }
     hipStream_t s = as_stream(stream);
 
     GemmP p;
@@ -608,11 +648,21 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     p.residual = (const float*)a->residual; p.r_rs = a->r_rs; p.r_b0 = a->r_b0; p.r_b1 = a->r_b1;
     p.C_pre = (float*)a->C_pre; p.aux = (const float*)a->aux;
     p.act = a->act; p.accumulate = a->accumulate;
+    p.n_group = a->n_group;
+    p.reduce_group = a->n_group && a->reduce_batch;
+    for (int g = 0; g < 4; ++g) {
+        const bool on = g < a->n_group;
+        p.Ag[g] = on ? (const float*)a->A_group[g] : nullptr;
+        p.Bg[g] = on ? (const float*)a->B_group[g] : nullptr;
+        p.Cg[g] = on ? (float*)a->C_group[g] : nullptr;
+        p.Sg[g] = on ? a->inv_scale_group[g] : nullptr;
+    }
     const int batch = a->batch0 * a->batch1;
     const bool akc = a->a_cs == 1;
     const bool bkc = a->b_cs == 1;
     bool vec = aligned16(a->A) && aligned16(a->B) && mult4(a->a_b0) && mult4(a->a_b1) && mult4(a->b_b0) &&
                mult4(a->b_b1);
+    for (int g = 0; g < a->n_group; ++g) vec = vec && aligned16(a->A_group[g]) && aligned16(a->B_group[g]);
     vec = vec && (akc ? (mult4(a->K) && mult4(a->a_rs)) : (mult4(a->M) && mult4(a->a_cs)));
     vec = vec && (bkc ? (mult4(a->K) && mult4(a->b_rs)) : (mult4(a->N) && mult4(a->b_cs)));
     // bf16-operand kernels need the 16-byte staging path; anything else runs on the exact fp32 kernels
@@ -629,12 +679,14 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     p.tiles_m = (a->M + BM - 1) / BM;
     const int pad128 = (a->N + 127) / 128 * 128, pad96 = (a->N + 95) / 96 * 96;
     int bn = pad96 < pad128 ? 96 : 128;
-    const bool k_split = a->reduce_batch || a->split_k > 1 ||
+    const bool grouped_reduce_unsplit = a->n_group && a->reduce_batch && a->split_k <= 1;
+    const bool k_split = (a->reduce_batch && !grouped_reduce_unsplit) || a->split_k > 1 ||
                          (a->split_k == 0 && batch == 1 && trivial_epi && p.tiles_m * ((a->N + bn - 1) / bn) < 256 &&
                           p.kpb >= 64);
     if (!k_split) {
         const long cus = 256;
-        const long items96 = (long)p.tiles_m * (pad96 / 96) * batch, items128 = (long)p.tiles_m * (pad128 / 128) * batch;
+        const long nb = grouped_reduce_unsplit ? 1 : batch;     // launches of the y grid dimension
+        const long items96 = (long)p.tiles_m * (pad96 / 96) * nb, items128 = (long)p.tiles_m * (pad128 / 128) * nb;
         const long cost96 = (items96 + cus - 1) / cus * 96, cost128 = (items128 + cus - 1) / cus * 128;
         bn = cost96 < cost128 ? 96 : 128;
     }
@@ -643,7 +695,9 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
 
     int nsplit = 1;
     p.atomic = 0;
-    if (a->reduce_batch) {
+    if (grouped_reduce_unsplit) {
+        p.kb_total = batch * p.kpb;                         // one k-range over all groups, plain epilogue
+    } else if (a->reduce_batch) {
         p.atomic = 1;
         p.kb_total = batch * p.kpb;
         nsplit = a->split_k > 1 ? a->split_k : 768 / tiles   /* one resident round: 256 CUs x 3 workgroups */;
@@ -670,6 +724,8 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
             else e = hipMemset2DAsync(p.C, sizeof(float) * a->c_rs, 0, sizeof(float) * a->N, a->M, s);
             if (e != hipSuccess) return (int)e;
         }
+    } else if (grouped_reduce_unsplit) {
+        p.kb_per_z = p.kb_total;                            // grid.y == 1
     } else {
         p.kb_per_z = p.kpb;   // grid.y == batch
     }

@@ -7,6 +7,7 @@ stay in the [B,S,H*hd] layout of the projection output (heads are addressed thro
 never materialised by a transpose).
 """
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -20,6 +21,9 @@ from .backend import ACT_GELU, ACT_GELU_BWD, ACT_NONE, get_backend
 # one call therefore always use the same arithmetic.
 _amp_fwd = torch.amp.custom_fwd(device_type="cuda")
 _amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+
+# grouped q/k/v launches (SNLinearGroupFn); CALM_GROUP_PROJECTIONS=0 restores one launch per projection (A/B switch)
+GROUP_PROJECTIONS = os.environ.get("CALM_GROUP_PROJECTIONS", "1") != "0"
 
 _noise_override = None
 
@@ -164,6 +168,58 @@ class SNLinearFn(Function):
         db = _colsum(be, dz) if ctx.has_bias else None
         dres = dy if ctx.has_res else None
         return dx, dW, db, d_ls, dres, None, None, None, None
+
+
+class SNLinearGroupFn(Function):
+    """y_g = x W_g^T / sigma_g for g = 0..n-1: the bias-free spectral-normed projections of a block that read the same
+    activation — q/k/v of a plain self-attention block, k/v of the others (Vi_Tools:265-267) — as ONE grouped launch
+    (more tiles per launch: fewer partly filled rounds), and their input gradient dx = sum_g dy_g W_g / sigma_g as one
+    pass over the concatenated reduction instead of n GEMMs plus n-1 gradient additions.
+    apply(x, w_0, u_0, v_0, sigma_0, w_1, ...) -> (y_0, ..., y_{n-1})"""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, x, *wuvs):
+        be = get_backend()
+        n = len(wuvs) // 4
+        ws, sigmas = list(wuvs[0::4]), list(wuvs[3::4])
+        x = _c(x)
+        K = x.shape[-1]
+        N = ws[0].shape[0]
+        assert all(w.shape == (N, K) for w in ws)
+        x2 = x.reshape(-1, K)
+        M = x2.shape[0]
+        outs = [torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device) for _ in range(n)]
+        be.gemm(x2, ws, [o.view(-1, N) for o in outs], M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), batch=(n, 1),
+                inv_scale=sigmas, split_k=1)
+        ctx.n = n
+        ctx.xshape = x.shape
+        ctx.save_for_backward(x2, *wuvs)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    @_amp_bwd
+    def backward(ctx, *dys):
+        be = get_backend()
+        x2, *wuvs = ctx.saved_tensors
+        n = ctx.n
+        ws, us, vs, sigmas = list(wuvs[0::4]), list(wuvs[1::4]), list(wuvs[2::4]), list(wuvs[3::4])
+        N, K = ws[0].shape
+        M = x2.shape[0]
+        dy2 = [_c(d).reshape(-1, N) for d in dys]
+        grads = []
+        for g in range(n):
+            G = torch.empty_like(ws[g])
+            _lin_wgrad(be, dy2[g], x2, G)
+            grads += [_sn_wbwd(be, G, ws[g], us[g], vs[g], sigmas[g])[0], None, None, None]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2)
+            be.gemm(dy2, ws, dx, M, K, N, (N, 1, 0, 0), (1, K, 0, 0), (K, 0, 0), batch=(n, 1), inv_scale=sigmas,
+                    reduce_batch=True, split_k=1)
+            dx = dx.view(ctx.xshape)
+        return (dx, *grads)
 
 
 class MlpFn(Function):

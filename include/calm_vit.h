@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CALM_ABI_VERSION 1
+#define CALM_ABI_VERSION 2
 
 #define CALM_E_INVAL   (-1)   /* null pointer / negative size                 */
 #define CALM_E_LAYOUT  (-2)   /* stride pattern the kernel cannot address     */
@@ -60,6 +60,15 @@ const char* calm_build_info(void);     /* "gfx950 ..." */
  * the sequence-axis linears.  split_k: 0 = library picks, 1 = off, >1 = that many K-slices; slices
  * and reduce_batch combine through fp32 atomics and then allow alpha/inv_scale only.
  *
+ * Grouped form (n_group = batch0 in 1..CALM_GEMM_MAX_GROUP; batch1 must be 1): the b0 entries are separate
+ * allocations — entry g uses A_group[g], B_group[g], C_group[g] (a table whose first entry is NULL falls back to
+ * base + g*stride) and its own spectral-norm scale inv_scale_group[g] (a NULL table entry = 1).
+ *   without reduce_batch: n_group independent products in ONE launch (the q/k/v projections of a block read one
+ *     activation: Vi_Tools_CNN_less_V2.py:265-267), each divided by its sigma in the epilogue;
+ *   with reduce_batch:    C = sum_g A_g B_g^T / sigma_g in one pass over the concatenated reduction (their
+ *     input gradient); runs unsplit — deterministic, full epilogue — unless split_k > 1.
+ * Grouped launches take no C_pre / aux / residual.
+ *
  * Replaces: nn.Linear / matmul / bmm call sites Vi_Tools_CNN_less_V2.py:226-231, 251-267, 276-277,
  * 288-290 (raw QK^T + linear_mask), 293-298 (QK^T, PV of SDPA), 300, 305-308, 312;
  * CALM_ViT_V2.py:76 (head), 1x1 convs Vi_Tools:380,384 — and all their autograd backward GEMMs.
@@ -83,7 +92,13 @@ typedef struct calm_gemm_args {
     int32_t reduce_batch;
     int32_t split_k;
     int32_t dtype;
+    int32_t n_group;             /* 0 = plain strided batches */
+    const void*  A_group[4];
+    const void*  B_group[4];
+    void*        C_group[4];
+    const float* inv_scale_group[4];
 } calm_gemm_args;
+#define CALM_GEMM_MAX_GROUP 4
 
 int calm_gemm(const calm_gemm_args* args, void* stream);
 

@@ -41,6 +41,37 @@ class EmulatedBackend:
     def gemm(self, A, B, Cout, M, N, K, a, b, c, batch=(1, 1), alpha=1.0, inv_scale=None, bias=None,
              col_scale=None, residual=None, r=(0, 0, 0), C_pre=None, aux=None, act=ACT_NONE,
              accumulate=False, reduce_batch=False, split_k=0):
+        lists = [t for t in (A, B, Cout, inv_scale) if isinstance(t, (list, tuple))]
+        if lists:                                           # grouped form (include/calm_vit.h)
+            n = len(lists[0])
+            assert batch == (n, 1) and C_pre is None and aux is None and residual is None
+            pick = lambda t, g: t[g] if isinstance(t, (list, tuple)) else t
+            one = lambda t, g, st: t if isinstance(t, (list, tuple)) or t is None else t.reshape(-1)[g * st:]
+            if not reduce_batch:
+                for g in range(n):
+                    Ag = pick(A, g) if isinstance(A, (list, tuple)) else one(A, g, a[2])
+                    Bg = pick(B, g) if isinstance(B, (list, tuple)) else one(B, g, b[2])
+                    Cg = pick(Cout, g) if isinstance(Cout, (list, tuple)) else one(Cout, g, c[1])
+                    self.gemm(Ag, Bg, Cg, M, N, K, a, b, c, alpha=alpha, inv_scale=pick(inv_scale, g), bias=bias,
+                              col_scale=col_scale, act=act, accumulate=accumulate, split_k=1)
+                return
+            total = None
+            for g in range(n):
+                Ag = pick(A, g) if isinstance(A, (list, tuple)) else one(A, g, a[2])
+                Bg = pick(B, g) if isinstance(B, (list, tuple)) else one(B, g, b[2])
+                part = torch.empty(M, N)
+                self.gemm(Ag, Bg, part, M, N, K, a, b, (N, 0, 0), alpha=alpha, inv_scale=pick(inv_scale, g), split_k=1)
+                total = part if total is None else total + part
+            Cv = _view(pick(Cout, 0), (1, 1, M, N), (0, 0, c[0], 1))
+            z = total
+            if bias is not None:
+                z = z + bias
+            if act == ACT_GELU:
+                z = _gelu(z)
+            if col_scale is not None:
+                z = z * col_scale
+            Cv.copy_(Cv + z if accumulate else z)
+            return
         b0, b1 = batch
         Av = _view(A, (b0, b1, M, K), (a[2], a[3], a[0], a[1]))
         Bv = _view(B, (b0, b1, N, K), (b[2], b[3], b[0], b[1]))

@@ -197,3 +197,28 @@ def test_reference_amp_step_with_grad_scaler():
         opt.zero_grad()
         losses.append(float(loss.detach()))
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("prec,tol", [("bf16", 2e-4), ("bf16x3", 5e-5)])
+def test_grouped_projection_gemm_on_the_bf16_pipe(prec, tol):
+    """Grouped q/k/v launch and its one-pass input gradient (per-group sigma) in the bf16-operand families."""
+    hip, emu = calm.backend.get_backend(), EmulatedBackend()
+    n, M, D = 3, 520, 96
+    x = rnd(M, D, seed=1)
+    ws = [rnd(D, D, seed=10 + g) / 8 for g in range(n)]
+    sig = [torch.tensor([0.7 + 0.4 * g]) for g in range(n)]
+    dys = [rnd(M, D, seed=20 + g) for g in range(n)]
+    lin = (D, 1, 0, 0)
+    calm.backend.set_matmul_precision(prec)
+    y_ref, y_hip = [torch.zeros(M, D) for _ in range(n)], [torch.zeros(M, D).cuda() for _ in range(n)]
+    emu.gemm(x, ws, y_ref, M, D, D, lin, lin, (D, 0, 0), batch=(n, 1), inv_scale=sig, split_k=1)
+    hip.gemm(x.cuda(), [w.cuda() for w in ws], y_hip, M, D, D, lin, lin, (D, 0, 0), batch=(n, 1),
+             inv_scale=[s.cuda() for s in sig], split_k=1)
+    dx_ref, dx_hip = torch.zeros(M, D), torch.zeros(M, D).cuda()
+    args = (M, D, D, lin, (1, D, 0, 0), (D, 0, 0))
+    emu.gemm(dys, ws, dx_ref, *args, batch=(n, 1), inv_scale=sig, reduce_batch=True, split_k=1)
+    hip.gemm([d.cuda() for d in dys], [w.cuda() for w in ws], dx_hip, *args, batch=(n, 1),
+             inv_scale=[s.cuda() for s in sig], reduce_batch=True, split_k=1)
+    for g in range(n):
+        assert rel_err(y_hip[g], y_ref[g]) < tol
+    assert rel_err(dx_hip, dx_ref) < tol
