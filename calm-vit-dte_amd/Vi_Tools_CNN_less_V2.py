@@ -76,6 +76,13 @@ class LayerNorm(torch.nn.Module):
     def forward(self, x):
         return ops.layer_norm(x, self.weight, self.eps)
 
+    def with_skip(self, x):
+        """(LayerNorm(x), x) — take the second value for the residual path that bypasses the norm: the two input
+        gradients are then summed inside the LayerNorm backward kernel (ops.LayerNormSkipFn)."""
+        if not (ops.FUSE_LN_SKIP and torch.is_grad_enabled() and x.requires_grad):
+            return self.forward(x), x
+        return ops.LayerNormSkipFn.apply(x, self.weight, self.eps)
+
 
 def _default_norm(dim, bias=False):
     return LayerNorm(dim, eps=1e-6, bias=bias)
@@ -238,8 +245,7 @@ class VMLA_Block(torch.nn.Module):
 
     def _forward(self, input_q, input_kv, state_manager):
         H = self.heads
-        residual = input_q
-        xq = self.ln_q(input_q)                                          # 210-215
+        xq, residual = self.ln_q.with_skip(input_q)                      # 209-215 (residual = input_q)
         xkv = xq if input_kv is None else self.ln_kv(input_kv)
         qz = qr = xq
         kz = vz = kr = xkv
@@ -284,9 +290,9 @@ class VMLA_Block(torch.nn.Module):
             if self.input_proj is not None:
                 residual = self.input_proj(residual)
         x = self.out_proj(x, ls=self.ls_att, residual=residual)          # 300, 309
-        y = self.ln_2(x)                                                 # 310-315
-        if self.mlp is None:
-            return y
+        if self.mlp is None:                                             # 310-315
+            return self.ln_2(x)
+        y, x = self.ln_2.with_skip(x)
         l0, l3 = self.mlp[0], self.mlp[3]
         return ops.MlpFn.apply(y, l0.weight_orig, None, l3.weight_orig, None, self.ls_mlp, x,
                                l0.weight_u, l0.weight_v, l0.sigma(), l3.weight_u, l3.weight_v, l3.sigma())

@@ -54,7 +54,7 @@ SIGNATURES = {
     "calm_build_info": (C.c_char_p, []),
     "calm_gemm": (_i32, [C.POINTER(GemmArgs), _p]),
     "calm_layernorm_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _f32, _p]),
-    "calm_layernorm_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
+    "calm_layernorm_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "calm_rope_fwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "calm_rope_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "calm_softmax_fwd": (_i32, [_p, _i64, _i32, _p]),

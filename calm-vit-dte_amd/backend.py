@@ -128,9 +128,9 @@ class HipBackend:
         _lib.check(self.lib.calm_layernorm_fwd(_ptr(x), _ptr(w), _ptr(y), _ptr(mean), _ptr(rstd), rows, D, eps,
                                                _stream()), "calm_layernorm_fwd")
 
-    def layernorm_bwd(self, dy, x, w, mean, rstd, dx, dw, rows, D):
+    def layernorm_bwd(self, dy, x, w, mean, rstd, dx, dw, rows, D, dx_add=None):
         _lib.check(self.lib.calm_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dx),
-                                               _ptr(dw), rows, D, _stream()), "calm_layernorm_bwd")
+                                               _ptr(dw), _ptr(dx_add, True), rows, D, _stream()), "calm_layernorm_bwd")
 
     # ---- RoPE -------------------------------------------------------------------------
     def rope_fwd(self, content, xr, inv_freq, table, out, B, S, H, dc, dr):

@@ -44,7 +44,8 @@ constexpr int LN_MAXC = 32;   // columns per lane kept in registers for dw (D <=
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                     const float* __restrict__ w, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, float* __restrict__ dx,
-                                                    float* __restrict__ dw, long rows, int D) {
+                                                    float* __restrict__ dw, const float* __restrict__ dx_add,
+                                                    long rows, int D) {
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     const long nwaves = (long)gridDim.x * (NT / 64);
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ dy
             if (c < D) {
                 const float xh = (xr[c] - mu) * rs;
                 const float gy = gr[c];
-                dr[c] = rs * (gy * w[c] - c1 - xh * c2);
+                dr[c] = rs * (gy * w[c] - c1 - xh * c2) + (dx_add ? dx_add[row * D + c] : 0.f);
                 dwacc[i] += gy * xh;
             }
         }
@@ -142,7 +143,8 @@ template <int NV>
 __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                         const float* __restrict__ w, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, float* __restrict__ dx,
-                                                        float* __restrict__ dw, long rows, int D) {
+                                                        float* __restrict__ dw, const float* __restrict__ dx_add,
+                                                        long rows, int D) {
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
     const long nwaves = (long)gridDim.x * (NT / 64);
@@ -175,14 +177,15 @@ __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const float* __restrict_
         }
         c1 = wave_sum(c1) / D; c2 = wave_sum(c2) / D;
         f32x4* dr = reinterpret_cast<f32x4*>(dx + row * D);
+        const f32x4* ar = dx_add ? reinterpret_cast<const f32x4*>(dx_add + row * D) : nullptr;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c4 = lane + 64 * i;
             if (c4 < nv4) {
-                f32x4 o;
+                f32x4 o = ar ? ar[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};      // gradient of the skip connection around LN
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    o[e] = rs * (gv[i][e] * wv[i][e] - c1 - xh[i][e] * c2);
+                    o[e] += rs * (gv[i][e] * wv[i][e] - c1 - xh[i][e] * c2);
                     dwacc[i][e] += gv[i][e] * xh[i][e];
                 }
                 dr[c4] = o;
@@ -495,26 +498,27 @@ int calm_layernorm_fwd(const float* x, const float* w, float* y, float* mean, fl
 }
 
 int calm_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
-                       float* dx, float* dw, int64_t rows, int32_t D, void* stream) {
+                       float* dx, float* dw, const float* dx_add, int64_t rows, int32_t D, void* stream) {
     if (!dy || !x || !w || !mean || !rstd || !dx || !dw || rows <= 0 || D <= 0) return CALM_E_INVAL;
     if (D > 64 * LN_MAXC) return CALM_E_UNSUPP;
     int g = grid_for(rows, NT / 64);
     if (g > 512) g = 512;
-    if ((D & 3) == 0 && D <= 256 * 5 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(w)) {
+    if ((D & 3) == 0 && D <= 256 * 5 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(w) &&
+        aligned16(dx_add)) {
         const dim3 gd(g), b(NT);
         hipStream_t s = as_stream(stream);
         const int nv = (D / 4 + 63) / 64;
         switch (nv) {
-            case 1: hipLaunchKernelGGL(ln_bwd_vec_kernel<1>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, (long)rows, D); break;
-            case 2: hipLaunchKernelGGL(ln_bwd_vec_kernel<2>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, (long)rows, D); break;
-            case 3: hipLaunchKernelGGL(ln_bwd_vec_kernel<3>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, (long)rows, D); break;
-            case 4: hipLaunchKernelGGL(ln_bwd_vec_kernel<4>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, (long)rows, D); break;
-            default: hipLaunchKernelGGL(ln_bwd_vec_kernel<5>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, (long)rows, D); break;
+            case 1: hipLaunchKernelGGL(ln_bwd_vec_kernel<1>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D); break;
+            case 2: hipLaunchKernelGGL(ln_bwd_vec_kernel<2>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D); break;
+            case 3: hipLaunchKernelGGL(ln_bwd_vec_kernel<3>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D); break;
+            case 4: hipLaunchKernelGGL(ln_bwd_vec_kernel<4>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D); break;
+            default: hipLaunchKernelGGL(ln_bwd_vec_kernel<5>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D); break;
         }
         CALM_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(g), dim3(NT), 0, as_stream(stream), dy, x, w, mean, rstd, dx, dw,
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(g), dim3(NT), 0, as_stream(stream), dy, x, w, mean, rstd, dx, dw, dx_add,
                        (long)rows, D);
     CALM_LAUNCH_CHECK();
     return 0;

@@ -24,6 +24,8 @@ _amp_bwd = torch.amp.custom_bwd(device_type="cuda")
 
 # grouped q/k/v launches (SNLinearGroupFn); CALM_GROUP_PROJECTIONS=0 restores one launch per projection (A/B switch)
 GROUP_PROJECTIONS = os.environ.get("CALM_GROUP_PROJECTIONS", "1") != "0"
+# skip-connection gradient summed inside the LayerNorm backward kernel (LayerNormSkipFn); =0: separate add (A/B switch)
+FUSE_LN_SKIP = os.environ.get("CALM_FUSE_LN_SKIP", "1") != "0"
 
 _noise_override = None
 
@@ -112,6 +114,44 @@ class LayerNormFn(Function):
         dx = torch.empty_like(x)
         dw = torch.zeros_like(w)
         be.layernorm_bwd(dy, x, w, mean, rstd, dx, dw, x.numel() // D, D)
+        return dx, dw, None
+
+
+class LayerNormSkipFn(Function):
+    """(LayerNorm(x), x): the norm together with the skip connection that bypasses it.  Every block feeds its input
+    both to a LayerNorm and to a residual add (Vi_Tools:209-211 with 309, 310-315), so autograd would sum the two
+    input gradients with one more elementwise pass; here the skip's gradient is added inside the LayerNorm backward
+    kernel (dx_add of calm_layernorm_bwd).  Use the second output wherever the reference re-uses x."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, x, w, eps):
+        be = get_backend()
+        x = _c(x)
+        D = x.shape[-1]
+        rows = x.numel() // D
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=x.dtype, device=x.device)
+        rstd = torch.empty_like(mean)
+        be.layernorm_fwd(x, w, y, mean, rstd, rows, D, eps)
+        ctx.save_for_backward(x, w, mean, rstd)
+        ctx.set_materialize_grads(False)
+        return y, x.view_as(x)
+
+    @staticmethod
+    @once_differentiable
+    @_amp_bwd
+    def backward(ctx, dy, dskip):
+        be = get_backend()
+        x, w, mean, rstd = ctx.saved_tensors
+        if dy is None:
+            return dskip, None, None
+        dy = _c(dy)
+        D = x.shape[-1]
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        be.layernorm_bwd(dy, x, w, mean, rstd, dx, dw, x.numel() // D, D,
+                         dx_add=_c(dskip).reshape(x.shape) if dskip is not None else None)
         return dx, dw, None
 
 

@@ -105,13 +105,16 @@ int calm_gemm(const calm_gemm_args* args, void* stream);
 /* ---------------------------------------------------------------------------------------
  * LayerNorm(D, eps, bias=False) over the last axis (Vi_Tools:131-132,197,494; fwd 211-215,311,523).
  * x,y: [rows, D] contiguous.  mean,rstd: [rows] saved for backward.
- * bwd: dx = rstd*(w*dy - mean_D(w*dy) - xhat*mean_D(w*dy*xhat)); dw[D] += sum_rows dy*xhat
- * (dw must be zeroed by the caller; accumulated with atomics).
+ * bwd: dx = rstd*(w*dy - mean_D(w*dy) - xhat*mean_D(w*dy*xhat)) [+ dx_add]; dw[D] += sum_rows dy*xhat
+ * (dw must be zeroed by the caller; accumulated with atomics).  dx_add (nullable, x's layout): gradient arriving
+ * through the skip connection that bypasses the norm (x feeds LN and the block's residual add, Vi_Tools:209-211,
+ * 309-315), summed into dx here instead of by a separate elementwise pass.
  * ------------------------------------------------------------------------------------- */
 int calm_layernorm_fwd(const float* x, const float* w, float* y, float* mean, float* rstd,
                        int64_t rows, int32_t D, float eps, void* stream);
 int calm_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean,
-                       const float* rstd, float* dx, float* dw, int64_t rows, int32_t D, void* stream);
+                       const float* rstd, float* dx, float* dw, const float* dx_add, int64_t rows, int32_t D,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Learned-frequency NeoX RoPE + head assembly (Vi_Tools:80-95 applied at 275-285).

@@ -121,13 +121,13 @@ class EmulatedBackend:
         mean.copy_(mu)
         rstd.copy_(rs)
 
-    def layernorm_bwd(self, dy, x, w, mean, rstd, dx, dw, rows, D):
+    def layernorm_bwd(self, dy, x, w, mean, rstd, dx, dw, rows, D, dx_add=None):
         x2, g2 = x.reshape(rows, D), dy.reshape(rows, D)
         xh = (x2 - mean[:, None]) * rstd[:, None]
         g = g2 * w
         c1 = g.mean(dim=1, keepdim=True)
         c2 = (g * xh).mean(dim=1, keepdim=True)
-        dx.view(rows, D).copy_(rstd[:, None] * (g - c1 - xh * c2))
+        dx.view(rows, D).copy_(rstd[:, None] * (g - c1 - xh * c2) + (dx_add.reshape(rows, D) if dx_add is not None else 0))
         dw.add_((g2 * xh).sum(dim=0))
 
     @staticmethod

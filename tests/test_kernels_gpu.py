@@ -156,6 +156,7 @@ def test_gemm_rejects_bad_arguments(hip):
                                     (33, 30), (9, 1302)])      # last two: scalar (D%4 != 0 / D > 1280) kernels
 def test_layernorm(hip, emu, rows, D):
     x, w, dy = rnd(rows, D, seed=1) * 2 + 0.5, 1 + 0.1 * rnd(D, seed=2), rnd(rows, D, seed=3)
+    skip = rnd(rows, D, seed=4)
     outs = []
     for be, dev in ((emu, "cpu"), (hip, "cuda")):
         X, Wt, DY = x.to(dev), w.to(dev), dy.to(dev)
@@ -163,9 +164,12 @@ def test_layernorm(hip, emu, rows, D):
         be.layernorm_fwd(X, Wt, y, mean, rstd, rows, D, 1e-6)
         dx, dw = torch.empty_like(X), torch.zeros(D, device=dev)
         be.layernorm_bwd(DY, X, Wt, mean, rstd, dx, dw, rows, D)
-        outs.append((y, mean, rstd, dx, dw))
+        dx2, dw2 = torch.empty_like(X), torch.zeros(D, device=dev)        # with the skip-connection gradient folded in
+        be.layernorm_bwd(DY, X, Wt, mean, rstd, dx2, dw2, rows, D, dx_add=skip.to(dev))
+        outs.append((y, mean, rstd, dx, dw, dx2, dw2))
     for a, b in zip(outs[1], outs[0]):
         assert rel_err(a, b) < TOL
+    assert rel_err(outs[1][5], outs[1][3] + skip.cuda()) < 1e-6
 
 
 @pytest.mark.parametrize("B,S,H,dc,dr", [(2, 48, 3, 0, 48), (2, 44, 3, 18, 18), (1, 224, 6, 56, 56), (3, 7, 2, 0, 6)])
