@@ -193,6 +193,9 @@ def main():
                          "bf16 operands (autocast arithmetic, configs #3-5), or the fp32-accurate bf16x3 split")
     ap.add_argument("--prof-steps", type=int, default=1)
     ap.add_argument("--graph", action="store_true", help="capture the whole step into a hipGraph (N=1 only)")
+    ap.add_argument("--torch-optim", action="store_true",
+                    help="clip_grad_norm_ + torch.optim.AdamW(fused) instead of the library's 3-launch optimizer-side "
+                         "step (calm_optim_step, which also folds in the spectral-norm gradient correction)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-report", default="", help="write a per-shape GEMM table (csv) from the profiled steps")
     args = ap.parse_args()
@@ -222,7 +225,7 @@ def main():
         step = trainer.GraphedTrainStep(model, opt, x, y)
         args.prof_steps = 0                                # events cannot be recorded inside a replayed graph
     else:
-        opt = trainer.make_optimizer(model)
+        opt = trainer.make_optimizer(model) if args.torch_optim else trainer.FusedClipAdamW(model)
         reducer = trainer.BucketedGradReducer(model) if world > 1 else None
         step = trainer.TrainStep(model, opt, reducer)
 
@@ -280,7 +283,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"CALM-ViT {args.workload} cls, {S}x{S}x3 synthetic, bs={batch}/GPU, "
                                    f"{args.precision} matmuls, fwd+loss+bwd+clip+AdamW", "global_batch": world * batch,
-                       "parallelism": f"dp{world}", "loss": float(loss), "hipgraph": bool(args.graph)},
+                       "parallelism": f"dp{world}", "loss": float(loss), "hipgraph": bool(args.graph),
+                       "optimizer": "torch clip_grad_norm_ + AdamW" if (args.torch_optim or args.graph)
+                       else "calm_optim_step (norm + clip + AdamW + spectral-norm grad correction, 3 launches)"},
             "model_tflops": round(value * wl["gflop_img"] / 1e3, 2),
             "roofline": roofline,
         }

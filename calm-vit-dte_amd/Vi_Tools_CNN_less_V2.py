@@ -205,6 +205,7 @@ class VMLA_Block(torch.nn.Module):
             SNLinear(seq_len_new * 2, seq_len_new, bias=True),
         )
         self.out_proj = SNLinear(dim2, dim2)
+        self.out_proj.layer_scaled = True            # combined with ls_att in one epilogue (see FusedClipAdamW)
         self.dropout = torch.nn.Dropout(dropout)
         self.ln_2 = LayerNorm(dim2)
         self.mlp = None
@@ -215,6 +216,7 @@ class VMLA_Block(torch.nn.Module):
                 torch.nn.Dropout(dropout, inplace=False),
                 SNLinear(mlp_dim, dim2),
             )
+            self.mlp[3].layer_scaled = True          # combined with ls_mlp
 
     @staticmethod
     def _seq(lin, x):

@@ -38,6 +38,18 @@ class GemmArgs(C.Structure):
     ]
 
 
+class OptimTensor(C.Structure):
+    """struct calm_optim_tensor (64 bytes)."""
+    _fields_ = [("param", _p), ("grad", _p), ("exp_avg", _p), ("exp_avg_sq", _p), ("sn_u", _p), ("sn_v", _p),
+                ("sn_sigma", _p), ("numel", _i64), ("rows", _i32), ("cols", _i32), ("chunk0", _i32), ("reserved", _i32)]
+
+
+class OptimHparams(C.Structure):
+    """struct calm_optim_hparams."""
+    _fields_ = [("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32),
+                ("max_norm", _f32), ("step", _i32)]
+
+
 class SnLayer(C.Structure):
     """struct calm_sn_layer."""
     _fields_ = [("w", _p), ("u", _p), ("v", _p), ("sigma", _p), ("rows", _i32), ("cols", _i32)]
@@ -69,6 +81,8 @@ SIGNATURES = {
     "calm_sn_plan": (_i32, [C.POINTER(SnLayer), _i32, _p, C.POINTER(SnPlanInfo)]),
     "calm_sn_power_iter": (_i32, [_p, C.POINTER(SnPlanInfo), _i32, _f32, _p, _p]),
     "calm_sn_weight_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p, _p]),
+    "calm_optim_chunk_elems": (_i32, []),
+    "calm_optim_step": (_i32, [_p, _i32, _p, _i32, _p, C.POINTER(OptimHparams), _p, _p, _p]),
     "calm_image_to_rows": (_i32, [_p, _p, _i32, _i32, _p]),
     "calm_rows_to_image": (_i32, [_p, _p, _i32, _i32, _p]),
     "calm_grid_transpose": (_i32, [_p, _p, _i32, _i32, _p]),

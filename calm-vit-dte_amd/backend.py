@@ -67,6 +67,35 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+class OptimPlan:
+    """Device table of calm_optim_tensor records for calm_optim_step; only the gradient pointers change per step."""
+
+    def __init__(self, be, records):
+        chunk = int(be.lib.calm_optim_chunk_elems())
+        self.n = len(records)
+        rec = np.zeros(self.n, dtype=np.dtype(_lib.OptimTensor))
+        chunk_tensor = []
+        for i, r in enumerate(records):
+            p = r["param"]
+            if not p.is_contiguous():
+                raise TypeError("optimizer-side step expects contiguous parameters")
+            e = rec[i]
+            e["param"], e["exp_avg"], e["exp_avg_sq"] = _ptr(p), _ptr(r["exp_avg"]), _ptr(r["exp_avg_sq"])
+            e["numel"] = p.numel()
+            if r["sn"] is not None:
+                u, v, sigma, rows, cols = r["sn"]
+                e["sn_u"], e["sn_v"], e["sn_sigma"], e["rows"], e["cols"] = _ptr(u), _ptr(v), _ptr(sigma), rows, cols
+            e["chunk0"] = len(chunk_tensor)
+            chunk_tensor += [i] * ((p.numel() + chunk - 1) // chunk)
+        dev = records[0]["param"].device
+        self.rec = rec
+        self.n_chunks = len(chunk_tensor)
+        self.chunk_dev = torch.tensor(chunk_tensor, dtype=torch.int32, device=dev)
+        self.host = torch.empty(rec.nbytes, dtype=torch.uint8).pin_memory()
+        self.table_dev = torch.empty(rec.nbytes, dtype=torch.uint8, device=dev)
+        self.scratch = torch.empty(6 * self.n + 4, dtype=torch.float32, device=dev)
+
+
 class SnPlan:
     """Device-resident plan for the batched spectral-norm power iteration."""
 
@@ -122,6 +151,21 @@ class HipBackend:
         g.split_k = split_k
         g.dtype = PRECISIONS[effective_precision()]
         _lib.check(self.lib.calm_gemm(C.byref(g), _stream()), "calm_gemm")
+
+    # ---- optimizer-side step ------------------------------------------------------------
+    def optim_plan(self, records):
+        """records: one dict per parameter — param, exp_avg, exp_avg_sq, sn (None or (u, v, sigma, rows, cols))."""
+        return OptimPlan(self, records)
+
+    def optim_step(self, plan, grads, hp, grad_scale, stats_out):
+        """hp = (lr, beta1, beta2, eps, weight_decay, max_norm, step); stats_out[2] <- grad norm, found_inf."""
+        plan.rec["grad"] = np.asarray([_ptr(g) for g in grads], dtype=np.uint64)
+        plan.host.numpy()[:] = plan.rec.view(np.uint8).reshape(-1)
+        plan.table_dev.copy_(plan.host, non_blocking=True)
+        h = _lib.OptimHparams(*hp)
+        _lib.check(self.lib.calm_optim_step(plan.table_dev.data_ptr(), plan.n, plan.chunk_dev.data_ptr(), plan.n_chunks,
+                                            _ptr(plan.scratch), C.byref(h), _ptr(grad_scale, True), _ptr(stats_out),
+                                            _stream()), "calm_optim_step")
 
     # ---- LayerNorm --------------------------------------------------------------------
     def layernorm_fwd(self, x, w, y, mean, rstd, rows, D, eps):

@@ -69,8 +69,18 @@ def _lin_wgrad(be, dy2, x2, G):
     be.gemm(dy2, x2, G, N, K, M, (1, N, 0, 0), (1, K, 0, 0), (K, 0, 0))
 
 
+# sigma.data_ptr() of the spectral-normed layers whose weight-gradient correction is applied later, by the fused
+# optimizer-side step (trainer.FusedClipAdamW registers them): their backward hands the gradient w.r.t. the
+# NORMALISED weight to autograd unchanged.
+DEFERRED_SN = set()
+
+
 def _sn_wbwd(be, G, w, u, v, sigma, ls=None):
     """G (grad wrt the effective weight, before LayerScale) -> (dW_orig, d_ls)."""
+    if DEFERRED_SN and sigma.data_ptr() in DEFERRED_SN:
+        if ls is not None:
+            raise RuntimeError("a layer used with LayerScale cannot defer its spectral-norm gradient")
+        return G.view_as(w), None
     rows = w.shape[0]
     cols = w.numel() // rows
     dW = torch.empty_like(w)

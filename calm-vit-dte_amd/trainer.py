@@ -184,6 +184,13 @@ class TrainStep:
             loss.backward()
         if self.reducer is not None:
             self.reducer.finish()
+        if isinstance(self.opt, FusedClipAdamW):                           # cls:88-96 in three launches
+            if self.scaler is not None:
+                raise NotImplementedError("FusedClipAdamW: pass scaler=None (gradients are fp32; bf16 autocast "
+                                          "needs no loss scaling) or call opt.step(grad_scale=...) yourself")
+            self.opt.max_norm = self.max_norm
+            self.opt.step()
+            return loss.detach(), y_hat.detach()
         if self.scaler is not None:
             self.scaler.unscale_(self.opt)                                 # cls:88
         torch.nn.utils.clip_grad_norm_(self.params, max_norm=self.max_norm, error_if_nonfinite=False)   # cls:92
@@ -202,6 +209,84 @@ def make_optimizer(model, lr=3.1e-3, weight_decay=0.02, betas=(0.9, 0.98), captu
     fused = params[0].is_cuda
     return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=betas, fused=fused,
                              capturable=capturable and fused)
+
+
+class FusedClipAdamW:
+    """unscale + inf/NaN check + clip_grad_norm_(max_norm) + AdamW + zero_grad of distributed_trainer_cls.py:88-96 as
+    THREE kernel launches over all parameters (calm_optim_step), with the spectral-norm weight-gradient correction
+    folded in: while an instance is live, the backward of every spectral-normed layer that is not combined with a
+    LayerScale leaves the gradient w.r.t. the normalised weight in `weight_orig.grad` (≈600 tiny launches per step
+    less) and this step applies dW_orig = (G - <G, W/sigma> u v^T)/sigma on the fly — so between backward and step()
+    those `.grad`s are NOT the reference's gradients; mean all-reduce commutes with the correction (it is linear and
+    u, v, sigma, W are replicated), so the BucketedGradReducer / DDP run unchanged in between.  close() restores the
+    in-backward correction.  Same update rule, hyper-parameters and state names as torch.optim.AdamW."""
+
+    def __init__(self, model, lr=3.1e-3, weight_decay=0.02, betas=(0.9, 0.98), eps=1e-8, max_norm=1.0, defer_sn=True):
+        from . import ops
+        from .backend import get_backend
+        from .spectral_norm import SpectralWeight
+        self.be = get_backend()
+        self.lr, self.weight_decay, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
+        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.step_count = 0
+        self.exp_avg = [torch.zeros_like(p) for p in self.params]
+        self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
+        sn = {}
+        if defer_sn:
+            for m in model.modules():
+                if isinstance(m, SpectralWeight) and not getattr(m, "layer_scaled", False):
+                    sn[id(m.weight_orig)] = m
+        records, self._deferred = [], []
+        for p, ea, eas in zip(self.params, self.exp_avg, self.exp_avg_sq):
+            m = sn.get(id(p))
+            info = None
+            if m is not None:
+                info = (m.weight_u, m.weight_v, m._sigma, m.rows, m.cols)
+                self._deferred.append(m._sigma.data_ptr())
+            records.append({"param": p.data, "exp_avg": ea, "exp_avg_sq": eas, "sn": info})
+        self._plan = self.be.optim_plan(records)
+        ops.DEFERRED_SN.update(self._deferred)
+        self._ops = ops
+        self.stats = torch.zeros(2, dtype=torch.float32, device=self.params[0].device)   # [grad norm, found_inf]
+
+    def close(self):
+        self._ops.DEFERRED_SN.difference_update(self._deferred)
+        self._deferred = []
+
+    @torch.no_grad()
+    def step(self, grad_scale=None):
+        """One optimizer-side step on the current `.grad`s; grads are released (set to None) afterwards.
+        grad_scale: device scalar the loss was multiplied by (GradScaler), or None.  Returns the stats tensor."""
+        grads = []
+        for p in self.params:
+            g = p.grad
+            if g is None:
+                g = p.grad = torch.zeros_like(p)
+            elif not g.is_contiguous():
+                g = p.grad = g.contiguous()
+            grads.append(g)
+        self.step_count += 1
+        hp = (self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_norm or 0.0, self.step_count)
+        self.be.optim_step(self._plan, grads, hp, grad_scale, self.stats)
+        for p in self.params:
+            p.grad = None
+        return self.stats
+
+    def zero_grad(self, set_to_none=True):
+        for p in self.params:
+            p.grad = None
+
+    def state_dict(self):
+        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
+                "hparams": dict(lr=self.lr, weight_decay=self.weight_decay, betas=self.betas, eps=self.eps,
+                                max_norm=self.max_norm)}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        for dst, src in zip(self.exp_avg, sd["exp_avg"]):
+            dst.copy_(src)
+        for dst, src in zip(self.exp_avg_sq, sd["exp_avg_sq"]):
+            dst.copy_(src)
 
 
 class GraphedTrainStep:

@@ -220,6 +220,42 @@ int calm_sn_weight_bwd(const float* G, const float* w_orig, const float* u, cons
                        int32_t rows, int32_t cols, float* scratch, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Optimizer-side step over ALL parameters in three launches (distributed_trainer_cls.py:88-96,158):
+ * GradScaler.unscale_ + inf/NaN check, clip_grad_norm_(max_norm), AdamW — torch.optim.AdamW's update exactly:
+ *   p *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps)
+ * with g = grad * min(1, max_norm/(||grad||+1e-6)) / grad_scale; the whole update is skipped when a gradient is
+ * inf/NaN (what scaler.step() does).  A tensor with sn_sigma != NULL carries the gradient w.r.t. its NORMALISED
+ * weight (backward deferred the correction): dW_orig = (G - <G, W_orig/sigma> u v^T)/sigma is applied on the fly
+ * and is what enters the norm.
+ *
+ * tensors_dev: table in device memory.  Work items are chunks of calm_optim_chunk_elems() consecutive elements of one
+ * tensor: chunk_tensor_dev[k] = tensor index of chunk k, tensor.chunk0 = its first chunk.
+ * scratch: 6*n_tensors + 4 floats (zeroed by the call).  stats_out[2] (device): total gradient norm, found_inf.
+ * ------------------------------------------------------------------------------------- */
+typedef struct calm_optim_tensor {
+    float*       param;
+    const float* grad;
+    float*       exp_avg;
+    float*       exp_avg_sq;
+    const float* sn_u;        /* [rows]  NULL for plain tensors */
+    const float* sn_v;        /* [cols] */
+    const float* sn_sigma;    /* [1] */
+    int64_t numel;
+    int32_t rows, cols;       /* rows*cols == numel for deferred spectral-norm weights */
+    int32_t chunk0, reserved;
+} calm_optim_tensor;
+
+typedef struct calm_optim_hparams {
+    float lr, beta1, beta2, eps, weight_decay, max_norm;   /* max_norm <= 0: no clipping */
+    int32_t step;                                           /* 1-based */
+} calm_optim_hparams;
+
+int32_t calm_optim_chunk_elems(void);
+int calm_optim_step(const calm_optim_tensor* tensors_dev, int32_t n_tensors, const int32_t* chunk_tensor_dev,
+                    int32_t n_chunks, float* scratch, const calm_optim_hparams* hparams,
+                    const float* grad_scale /* device scalar or NULL */, float* stats_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Tokenisation (bit-exact index work).
  * image_to_rows : rows[b,i,3j+c] = img[b,c,i,j]           (Vi_Tools:389-391); rows_to_image inverse.
  * grid_transpose: out[b,j,3i+c]  = in[b,i,3j+c]           (Vi_Tools:394-395,397-398; self-inverse)

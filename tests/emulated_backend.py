@@ -112,6 +112,36 @@ class EmulatedBackend:
             z = z + Cv
         Cv.copy_(z)
 
+    def optim_plan(self, records):
+        return records
+
+    def optim_step(self, plan, grads, hp, grad_scale, stats_out):
+        """calm_optim_step: deferred spectral-norm correction, global norm, clip, torch.optim.AdamW's update."""
+        lr, b1, b2, eps, wd, max_norm, step = hp
+        fixed = []
+        for r, g in zip(plan, grads):
+            if r["sn"] is not None:
+                u, v, sigma, rows, cols = r["sn"]
+                G, Wm = g.reshape(rows, cols), r["param"].reshape(rows, cols)
+                c = (G * Wm).sum() / sigma
+                g = ((G - c * torch.outer(u, v)) / sigma).reshape(g.shape)
+            fixed.append(g)
+        inv = 1.0 / float(grad_scale) if grad_scale is not None else 1.0
+        norm = torch.sqrt(sum((g.double() ** 2).sum() for g in fixed)).float() * inv
+        bad = not bool(torch.isfinite(norm))
+        stats_out[0], stats_out[1] = norm, float(bad)
+        if bad:
+            return
+        mul = (min(1.0, max_norm / (float(norm) + 1e-6)) if max_norm > 0 else 1.0) * inv
+        bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
+        for r, g in zip(plan, fixed):
+            g = g * mul
+            p, m, v = r["param"], r["exp_avg"], r["exp_avg_sq"]
+            p.mul_(1 - lr * wd)
+            m.lerp_(g, 1 - b1)
+            v.mul_(b2).addcmul_(g, g, value=1 - b2)
+            p.addcdiv_(m, (v.sqrt() / (bc2 ** 0.5)).add_(eps), value=-lr / bc1)
+
     def layernorm_fwd(self, x, w, y, mean, rstd, rows, D, eps):
         x2 = x.reshape(rows, D)
         mu = x2.mean(dim=1)

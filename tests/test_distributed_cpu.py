@@ -27,7 +27,7 @@ def _setup_path():
             sys.path.insert(0, p)
 
 
-def _run_steps(rank, world, x, y, steps, bucket_mb, stock_ddp=False):
+def _run_steps(rank, world, x, y, steps, bucket_mb, stock_ddp=False, fused_optim=False):
     from importlib import import_module
     import calm_vit_dte_amd as calm
     from emulated_backend import EmulatedBackend
@@ -49,16 +49,22 @@ def _run_steps(rank, world, x, y, steps, bucket_mb, stock_ddp=False):
             step.params = [p for p in m.parameters() if p.requires_grad]
         else:
             trainer.sync_module_states(m)
-            opt = trainer.make_optimizer(m)
+            # fused_optim: gradients of the spectral-normed weights stay un-corrected through the all-reduce and are
+            # corrected inside the optimizer-side step (mean all-reduce commutes with the linear correction)
+            opt = trainer.FusedClipAdamW(m) if fused_optim else trainer.make_optimizer(m)
             red = trainer.BucketedGradReducer(m, bucket_mb=bucket_mb) if world > 1 else None
             step = trainer.TrainStep(m, opt, red)
         n = x.shape[0] // world
         xs, ys = x[rank * n:(rank + 1) * n], y[rank * n:(rank + 1) * n]
-        losses = [float(step(xs, ys)[0]) for _ in range(steps)]
+        try:
+            losses = [float(step(xs, ys)[0]) for _ in range(steps)]
+        finally:
+            if fused_optim:
+                opt.close()
     return m, losses
 
 
-def _worker(rank, world, port, x, y, steps, outdir, stock_ddp=False):
+def _worker(rank, world, port, x, y, steps, outdir, stock_ddp=False, fused_optim=False):
     _setup_path()
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
@@ -67,22 +73,23 @@ def _worker(rank, world, port, x, y, steps, outdir, stock_ddp=False):
     trainer = import_module("calm_vit_dte_amd.trainer")
     r, lr, w = trainer.init_distributed(use_gpu=False)
     assert (r, w) == (rank, world)
-    m, losses = _run_steps(rank, world, x, y, steps, bucket_mb=1, stock_ddp=stock_ddp)   # 1 MiB buckets -> several
+    m, losses = _run_steps(rank, world, x, y, steps, bucket_mb=1, stock_ddp=stock_ddp, fused_optim=fused_optim)   # 1 MiB buckets -> several
     torch.save({"sd": m.state_dict(), "losses": losses}, os.path.join(outdir, f"rank{rank}.pt"))
     import torch.distributed as dist
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("stock_ddp", [False, True], ids=["bucketed_reducer", "torch_DDP_wrapper"])
-def test_two_rank_gloo_training_matches_single_process(tmp_path, stock_ddp):
+@pytest.mark.parametrize("stock_ddp,fused_optim", [(False, False), (True, False), (False, True)],
+                         ids=["bucketed_reducer", "torch_DDP_wrapper", "bucketed_reducer+fused_optimizer_step"])
+def test_two_rank_gloo_training_matches_single_process(tmp_path, stock_ddp, fused_optim):
     _setup_path()
     import numpy as np
     g = np.random.default_rng(0)
     x = torch.from_numpy(g.standard_normal((8, 3, 32, 32)).astype(np.float32))          # bs=8, CIFAR-shaped
     y = torch.nn.functional.one_hot(torch.from_numpy(g.integers(0, 10, 8)), 10).float() * 0.9 + 0.01
     steps = 2
-    mp.spawn(_worker, args=(2, _free_port(), x, y, steps, str(tmp_path), stock_ddp), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), x, y, steps, str(tmp_path), stock_ddp, fused_optim), nprocs=2, join=True)
     r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
     r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
     for k in r0["sd"]:

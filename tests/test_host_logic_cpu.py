@@ -90,3 +90,36 @@ def test_train_forward_backward_matches_golden(name):
             assert rel_err(params[key[5:]].grad, g[key]) < 1e-4, key
         if key.startswith("post/"):
             assert rel_err(sd[key[5:]], g[key]) < 2e-5, key
+
+
+def test_fused_optimizer_step_defers_spectral_norm_gradient_and_matches_torch():
+    """trainer.FusedClipAdamW (host side of calm_optim_step) with the emulated backend: backward leaves the gradient
+    w.r.t. the normalised weights, the step corrects it, and the parameters end where
+    backward -> clip_grad_norm_(1.0) -> torch.optim.AdamW.step() (distributed_trainer_cls.py:87-96) puts them."""
+    from importlib import import_module
+    trainer = import_module("calm_vit_dte_amd.trainer")
+    name = "tiny32_cls"
+    g = load_golden(name)
+    cfg = CONFIGS[name]
+    rng = np.random.default_rng(3)
+    x = torch.from_numpy(rng.standard_normal((4, 3, cfg.seq_length, cfg.seq_length)).astype(np.float32))
+    y = torch.nn.functional.one_hot(torch.from_numpy(rng.integers(0, cfg.out_features, 4)), cfg.out_features).float()
+    results = []
+    with calm.backend.use_backend(EmulatedBackend()):
+        for fused in (False, True):
+            m = build_model(name, g).train()
+            opt = trainer.FusedClipAdamW(m) if fused else trainer.make_optimizer(m)
+            step = trainer.TrainStep(m, opt, None)
+            try:
+                for _ in range(2):
+                    step(x, y)
+                if fused:
+                    assert float(opt.stats[0]) > 0 and float(opt.stats[1]) == 0
+                    assert len(opt._deferred) > 100 and calm.ops.DEFERRED_SN
+            finally:
+                if fused:
+                    opt.close()
+            results.append({k: v.clone() for k, v in m.state_dict().items()})
+    assert not calm.ops.DEFERRED_SN
+    worst = max((rel_err(results[1][k], results[0][k]), k) for k in results[0])
+    assert worst[0] < 1e-4, worst                          # Adam amplifies fp32 rounding of near-zero gradients
