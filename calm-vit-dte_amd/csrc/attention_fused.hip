@@ -644,10 +644,14 @@ int launch_bwd(const AttnBwdP& p, hipStream_t s) {
 }
 
 #ifndef ATT_NW11
-#define ATT_NW11 6     // waves per workgroup for the 11-tile (S=176) instantiation; A/B'd against 4
+#define ATT_NW11 11    // waves per workgroup for the 11-tile (S=176) instantiation: one wave per query tile, a single
+#endif                 // pass (A/B: 684 -> 473 us against 6 waves in two passes; 4 waves: slower still)
+#ifndef ATT_NW14
+#define ATT_NW14 7     // 14-tile (S=224) instantiation
 #endif
 inline int pick_waves(int tiles) {
     if (tiles == 11) return ATT_NW11;
+    if (tiles == 14) return ATT_NW14;
     const int groups = (tiles + 7) / 8;
     return (tiles + groups - 1) / groups;
 }
@@ -708,7 +712,7 @@ int calm_attention_fwd(const float* q, const float* k, const float* v, const flo
         case 5: return launch_fwd<5, 5>(p, s);
         case 8: return launch_fwd<8, 8>(p, s);
         case 11: return launch_fwd<11, ATT_NW11>(p, s);
-        case 14: return launch_fwd<14, 7>(p, s);
+        case 14: return launch_fwd<14, ATT_NW14>(p, s);
     }
     return CALM_E_UNSUPP;
 }
@@ -734,7 +738,7 @@ int calm_attention_bwd(const float* q, const float* k, const float* v, const flo
         case 5: return launch_bwd<5, 5>(p, s);
         case 8: return launch_bwd<8, 8>(p, s);
         case 11: return launch_bwd<11, ATT_NW11>(p, s);
-        case 14: return launch_bwd<14, 7>(p, s);
+        case 14: return launch_bwd<14, ATT_NW14>(p, s);
     }
     return CALM_E_UNSUPP;
 }
