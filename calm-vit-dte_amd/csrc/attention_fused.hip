@@ -721,7 +721,10 @@ int calm_attention_fwd(const float* q, const float* k, const float* v, const flo
 // for head dims <= 64 (S=128/80 stages of Small-224, every stage of Base-224: 1.1-1.7x) and tie or lose above
 // (hd 112: 1.00x, hd 88: 0.76x), where the per-head GEMMs already fill 128-wide tiles.
 int calm_attention_bwd_preferred(int32_t Sq, int32_t Skv, int32_t H, int32_t hd) {
-    return calm_attention_fwd_supported(Sq, Skv, H, hd) && hd <= 64;
+    // measured against the composition of batched GEMMs + softmax_bwd + sum_heads (scripts/ab_attn_bwd.py): faster for
+    // head dims <= 64 (1.0-1.6x) and for the 11-tile stage (S=176, hd 88: 0.68 vs 0.77 ms, one wave per key/query
+    // tile); at S=224 with hd 112 the composition still wins (1.36 vs 1.43 ms)
+    return calm_attention_fwd_supported(Sq, Skv, H, hd) && (hd <= 64 || Skv / 16 == 11);
 }
 
 int calm_attention_bwd(const float* q, const float* k, const float* v, const float* dout, const float* P, float* dS,
