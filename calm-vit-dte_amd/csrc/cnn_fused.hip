@@ -26,6 +26,13 @@ struct CnnW {
 
 __device__ __forceinline__ f32x2 gelu2(f32x2 z) { return (f32x2){gelu_erf_f(z[0]), gelu_erf_f(z[1])}; }
 __device__ __forceinline__ f32x2 gelu2_grad(f32x2 z) { return (f32x2){gelu_erf_grad_f(z[0]), gelu_erf_grad_f(z[1])}; }
+__device__ __forceinline__ void gelu2_both(f32x2 z, f32x2& val, f32x2& grad) {      // one exp / rcp per element for both
+    float c0, g0, c1, g1;
+    gelu_parts_f(z[0], c0, g0);
+    gelu_parts_f(z[1], c1, g1);
+    val = (f32x2){z[0] * c0, z[1] * c1};
+    grad = (f32x2){fmaf(z[0] * 0.39894228040143267794f, g0, c0), fmaf(z[1] * 0.39894228040143267794f, g1, c1)};
+}
 __device__ __forceinline__ f32x2 ld2(const float* p) { return *reinterpret_cast<const f32x2*>(p); }
 __device__ __forceinline__ void st2(float* p, f32x2 v) { *reinterpret_cast<f32x2*>(p) = v; }
 
@@ -193,11 +200,12 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
                 }
             const float d0 = dys[3 * r], d1 = dys[3 * r + 1], d2 = dys[3 * r + 2];
             const f32x2 dh2 = w4r[0] * d0 + w4r[1] * d1 + w4r[2] * d2;
-            const f32x2 dz = in ? dh2 * gelu2_grad(z) : zero2;
+            f32x2 h2, dgelu;
+            gelu2_both(z, h2, dgelu);
+            const f32x2 dz = in ? dh2 * dgelu : zero2;
             st2(&d2s[r * PS + c], dz);
             const bool own = in && ry >= 1 && ry <= T && rx >= 1 && rx <= T;
             if (own) {
-                const f32x2 h2 = gelu2(z);
                 a_g4[0] += h2 * d0; a_g4[1] += h2 * d1; a_g4[2] += h2 * d2;
                 a_gb2 += dz;
 #pragma unroll
