@@ -130,8 +130,10 @@ __device__ __forceinline__ void load_operand(const float* __restrict__ base, lon
     }
 }
 
-template <bool KC, int VEC>
-__device__ __forceinline__ void store_operand(float (*T)[LDT], const float (&reg)[NREG]) {
+// ROWS = rows of the tile this operand stages (128, or 96 for the B side of the 128x96 tile): the 128-row thread
+// mapping is shared, rows past ROWS are simply not stored (their image row stride LD may be too short for them).
+template <bool KC, int VEC, int LD, int ROWS>
+__device__ __forceinline__ void store_operand(float (*T)[LD], const float (&reg)[NREG]) {
     const int tid = threadIdx.x;
     if constexpr (VEC == 4) {
         if constexpr (KC) {
@@ -140,11 +142,13 @@ __device__ __forceinline__ void store_operand(float (*T)[LDT], const float (&reg
 #pragma unroll
             for (int i = 0; i < NREG / 4; ++i) {
                 const int row = (tid / KQ) + RPP * i;
+                if (ROWS < 128 && row >= ROWS) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) T[kq + j][row] = reg[4 * i + j];
             }
         } else {
             const int row = 4 * (tid & 31);
+            if (ROWS < 128 && row >= ROWS) return;
 #pragma unroll
             for (int i = 0; i < NREG / 4; ++i) {
                 const int k = (tid >> 5) + 8 * i;
@@ -156,9 +160,14 @@ __device__ __forceinline__ void store_operand(float (*T)[LDT], const float (&reg
         if constexpr (KC) {
             const int k = tid % BK;
 #pragma unroll
-            for (int i = 0; i < NREG; ++i) T[k][(tid / BK) + (NTHREADS / BK) * i] = reg[i];
+            for (int i = 0; i < NREG; ++i) {
+                const int row = (tid / BK) + (NTHREADS / BK) * i;
+                if (ROWS < 128 && row >= ROWS) continue;
+                T[k][row] = reg[i];
+            }
         } else {
             const int row = tid & 127;
+            if (ROWS < 128 && row >= ROWS) return;
 #pragma unroll
             for (int i = 0; i < NREG; ++i) T[(tid >> 7) + 2 * i][row] = reg[i];
         }
@@ -263,15 +272,19 @@ template <bool AKC, bool BKC, int VEC, int BN_>
 #ifndef CALM_GEMM_WAVES
 #define CALM_GEMM_WAVES 4
 #endif
+#ifndef CALM_GEMM_WAVES96
+#define CALM_GEMM_WAVES96 5      // 128x96 tile: B image at its own row stride (29.7 KB LDS) and <=96 VGPRs -> 5 workgroups per CU (A/B -1.3% time)
+#endif
 #ifndef CALM_GEMM_BF16_WAVES
 #define CALM_GEMM_BF16_WAVES 3      // bf16-operand family: 3 (A/B: bf16 -4% time; 4 spills; bf16x3 is LDS-limited to 2 either way)
 #endif
-__global__ __launch_bounds__(NTHREADS, CALM_GEMM_WAVES) void gemm_f32_kernel(const GemmP p) {
+__global__ __launch_bounds__(NTHREADS, BN_ == 96 ? CALM_GEMM_WAVES96 : CALM_GEMM_WAVES) void gemm_f32_kernel(const GemmP p) {
     constexpr int WN = BN_ == 128 ? 2 : 1;        // wave grid: 2x2 (128x128 tile) or 4x1 (128x96 tile)
     constexpr int MT = BN_ == 128 ? 2 : 1;        // 32x32 MFMA tiles per wave along M
     constexpr int NT = BN_ / (WN * 32);           // ... along N (2 or 3)
+    constexpr int LDB = BN_ == 128 ? LDT : 100;   // B image row stride: 96 columns need no more (100 = 4 mod 32 banks too)
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
@@ -325,8 +338,8 @@ __global__ __launch_bounds__(NTHREADS, CALM_GEMM_WAVES) void gemm_f32_kernel(con
     int buf = 0;
     if (kb_begin < kb_end) {
         fetch(kb_begin);
-        store_operand<AKC, VEC>(As[0], ra);
-        store_operand<BKC, VEC>(Bs[0], rb);
+        store_operand<AKC, VEC, LDT, BM>(As[0], ra);
+        store_operand<BKC, VEC, LDB, BN_>(Bs[0], rb);
     }
     __syncthreads();
     STAMP_REAL(t_loop);
@@ -372,8 +385,8 @@ __global__ __launch_bounds__(NTHREADS, CALM_GEMM_WAVES) void gemm_f32_kernel(con
         STAMP(s3);
 #if !(CALM_GEMM_ABLATE & 2)
         if (more) {
-            store_operand<AKC, VEC>(As[buf ^ 1], ra);
-            store_operand<BKC, VEC>(Bs[buf ^ 1], rb);
+            store_operand<AKC, VEC, LDT, BM>(As[buf ^ 1], ra);
+            store_operand<BKC, VEC, LDB, BN_>(Bs[buf ^ 1], rb);
         }
 #endif
         STAMP(s4);
@@ -693,6 +706,9 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     p.tiles_n = (a->N + bn - 1) / bn;
     const int tiles = p.tiles_m * p.tiles_n;
 
+    // k-slices of a split launch: one resident round of workgroups (256 CUs x 5 for the 96-wide tile, x 4 for the
+    // 128-wide one; A/B over the weight-gradient shapes: -3% time against 768, -12% on 1344x672)
+    const int split_slots = bn == 96 ? 256 * CALM_GEMM_WAVES96 : 256 * CALM_GEMM_WAVES;
     int nsplit = 1;
     p.atomic = 0;
     if (grouped_reduce_unsplit) {
@@ -700,13 +716,13 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     } else if (a->reduce_batch) {
         p.atomic = 1;
         p.kb_total = batch * p.kpb;
-        nsplit = a->split_k > 1 ? a->split_k : 768 / tiles   /* one resident round: 256 CUs x 3 workgroups */;
+        nsplit = a->split_k > 1 ? a->split_k : split_slots / tiles;
         const int max_split = (p.kb_total + 7) / 8;
         if (nsplit > max_split) nsplit = max_split;
         if (nsplit < 1) nsplit = 1;
     } else if (k_split) {
         if (batch != 1) return CALM_E_UNSUPP;
-        nsplit = a->split_k > 1 ? a->split_k : 768 / tiles;
+        nsplit = a->split_k > 1 ? a->split_k : split_slots / tiles;
         const int max_split = (p.kpb + 15) / 16;
         if (nsplit > max_split) nsplit = max_split;
         if (nsplit < 1) nsplit = 1;
