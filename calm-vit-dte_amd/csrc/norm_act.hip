@@ -418,6 +418,9 @@ __global__ __launch_bounds__(NT) void gelu_bwd_kernel(const float* __restrict__ 
 }
 
 constexpr int COLSUM_MAXC = 4096;
+#ifndef COLSUM_GRID
+#define COLSUM_GRID 128      // A/B on [57344,448]: 66 us (scalar form) -> 28.6 us; 256 blocks: 39.6 (atomics), 128x256 threads: 34
+#endif
 __global__ __launch_bounds__(NT) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows,
                                                     int cols) {
     __shared__ float acc[COLSUM_MAXC];
@@ -437,6 +440,42 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const float* __restrict__ x,
     }
     __syncthreads();
     for (int c = threadIdx.x; c < cols; c += NT) atomicAdd(out + c, acc[c]);
+}
+
+// 16-byte form: TX lanes across the row (one float4 each, several passes if the row is longer), 1024/TX row lanes,
+// four rows in flight per thread; partial sums meet in LDS, one atomic per column per block.
+constexpr int CS_NT = 1024;          // 16 waves per block: few blocks (few atomics per column), many rows in flight
+template <int TX>
+__global__ __launch_bounds__(CS_NT) void colsum_vec_kernel(const float* __restrict__ x, float* __restrict__ out, long rows,
+                                                        int cols) {
+    constexpr int TY = CS_NT / TX;
+    __shared__ f32x4 part[CS_NT];
+    const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
+    const int c4n = cols >> 2;
+    const long rstep = (long)gridDim.x * TY;
+    for (int c4 = tx; c4 < ((c4n + TX - 1) / TX) * TX; c4 += TX) {
+        f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+        if (c4 < c4n) {
+            long r = (long)blockIdx.x * TY + ty;
+            for (; r + 3 * rstep < rows; r += 4 * rstep) {
+                a0 += reinterpret_cast<const f32x4*>(x + r * cols)[c4];
+                a1 += reinterpret_cast<const f32x4*>(x + (r + rstep) * cols)[c4];
+                a2 += reinterpret_cast<const f32x4*>(x + (r + 2 * rstep) * cols)[c4];
+                a3 += reinterpret_cast<const f32x4*>(x + (r + 3 * rstep) * cols)[c4];
+            }
+            for (; r < rows; r += rstep) a0 += reinterpret_cast<const f32x4*>(x + r * cols)[c4];
+        }
+        part[threadIdx.x] = (a0 + a1) + (a2 + a3);
+        __syncthreads();
+        if (ty == 0 && c4 < c4n) {
+            f32x4 s = part[tx];
+#pragma unroll
+            for (int k = 1; k < TY; ++k) s += part[k * TX + tx];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(out + 4 * c4 + e, s[e]);
+        }
+        __syncthreads();
+    }
 }
 
 __global__ __launch_bounds__(NT) void row_scale_kernel(const float* __restrict__ x, const float* __restrict__ s,
@@ -622,6 +661,22 @@ int calm_gelu_bwd(const float* dy, const float* z, float* dz, int64_t n, void* s
 int calm_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* stream) {
     if (!x || !out || rows <= 0 || cols <= 0) return CALM_E_INVAL;
     if (cols > COLSUM_MAXC) return CALM_E_UNSUPP;
+    if ((cols & 3) == 0 && aligned16(x) && rows >= 64) {
+        const int c4n = cols >> 2;
+        const int tx = c4n <= 32 ? 32 : c4n <= 64 ? 64 : c4n <= 128 ? 128 : 256;
+        const int ty = CS_NT / tx;
+        long gl = (rows + (long)ty * 8 - 1) / ((long)ty * 8);          // >= 8 rows per row lane
+        const int gv = (int)(gl < 1 ? 1 : gl > COLSUM_GRID ? COLSUM_GRID : gl);   // few blocks: every block ends in `cols` atomics
+        hipStream_t s = as_stream(stream);
+        switch (tx) {
+            case 32: hipLaunchKernelGGL(colsum_vec_kernel<32>, dim3(gv), dim3(CS_NT), 0, s, x, out, (long)rows, cols); break;
+            case 64: hipLaunchKernelGGL(colsum_vec_kernel<64>, dim3(gv), dim3(CS_NT), 0, s, x, out, (long)rows, cols); break;
+            case 128: hipLaunchKernelGGL(colsum_vec_kernel<128>, dim3(gv), dim3(CS_NT), 0, s, x, out, (long)rows, cols); break;
+            default: hipLaunchKernelGGL(colsum_vec_kernel<256>, dim3(gv), dim3(CS_NT), 0, s, x, out, (long)rows, cols); break;
+        }
+        CALM_LAUNCH_CHECK();
+        return 0;
+    }
     int g = cols >= NT ? (int)(rows < 512 ? rows : 512) : grid_for(rows * cols, NT * 8);
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(colsum_kernel, dim3(g), dim3(NT), 0, as_stream(stream), x, out, (long)rows, cols);

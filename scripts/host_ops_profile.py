@@ -1,29 +1,38 @@
 #!/usr/bin/env python3
-"""Which ATen ops (outside the library's kernels) run per training step, and how many launches they cost."""
+"""Which host-side call sites issue the small aten fill / copy / add launches of one training step?
+(torch profiler with Python stacks on the Nano-48 model: the host code path is the same for every configuration)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
     sys.path.insert(0, p)
-import importlib.util, torch
-spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py")); bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
-import calm_vit_dte_amd as calm
+from collections import Counter
 from importlib import import_module
+import torch
+from torch.profiler import profile, ProfilerActivity
+import calm_vit_dte_amd as calm
+from helpers import CONFIGS, load_golden
+from test_host_logic_cpu import build_model
+
 trainer = import_module("calm_vit_dte_amd.trainer")
-wl = bench.WORKLOADS["small224"]
-dev = torch.device("cuda", 0)
-model = bench.build_model(calm, wl["kw"], dev).train()
-opt = trainer.make_optimizer(model)
-step = trainer.TrainStep(model, opt, None)
-x, y = bench.synthetic_batch(32, 224, 1000, 0, dev)
+name = "nano48_cls"
+g = load_golden(name)
+cfg = CONFIGS[name]
+x = torch.randn(4, 3, 48, 48, device="cuda")
+y = torch.nn.functional.one_hot(torch.tensor([1, 2, 3, 4]), cfg.out_features).float().cuda()
+m = build_model(name, g, "cuda").train()
+opt = trainer.FusedClipAdamW(m)
+step = trainer.TrainStep(m, opt, None)
 for _ in range(2):
     step(x, y)
 torch.cuda.synchronize()
-from torch.profiler import profile, ProfilerActivity
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU], with_stack=True) as prof:
     step(x, y)
-    torch.cuda.synchronize()
-rows = [(e.key, e.count, e.self_cpu_time_total, getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0))) for e in prof.key_averages()]
-rows.sort(key=lambda r: -r[1])
-print(f"{'op':60s} {'calls':>6s} {'self_cpu_ms':>11s} {'self_gpu_ms':>11s}")
-for k, n, c, g in rows[:45]:
-    print(f"{k[:60]:60s} {n:6d} {c/1e3:11.2f} {g/1e3:11.2f}")
+torch.cuda.synchronize()
+watch = ("aten::fill_", "aten::zero_", "aten::copy_", "aten::add", "aten::add_", "aten::mul", "aten::clone", "aten::contiguous")
+c = Counter()
+for e in prof.events():
+    if e.name in watch:
+        st = [s for s in (e.stack or []) if "calm-vit-dte_amd" in s]
+        c[(e.name, st[0].split("calm-vit-dte_amd/")[-1] if st else "<torch internal / autograd>")] += 1
+for (n, s), k in sorted(c.items(), key=lambda t: -t[1])[:45]:
+    print(f"{k:5d} {n:16s} {s[:110]}")

@@ -313,7 +313,7 @@ def test_streaming_helpers(hip, emu):
     emu.gelu_bwd(a, b, dz_ref, n)
     hip.gelu_bwd(a.cuda(), b.cuda(), dz, n)
     assert rel_err(dz, dz_ref) < TOL
-    for rows, cols in ((500, 3), (300, 32), (77, 448), (40, 1000)):
+    for rows, cols in ((500, 3), (300, 32), (77, 448), (40, 1000), (4096, 448), (1000, 120), (3000, 1344), (513, 2000), (100, 4)):
         x = rnd(rows, cols, seed=3)
         s_ref, s_hip = torch.zeros(cols), torch.zeros(cols).cuda()
         emu.colsum(x, s_ref, rows, cols)
