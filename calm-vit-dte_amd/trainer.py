@@ -178,6 +178,10 @@ class TrainStep:
                             enabled=self.autocast_dtype is not None and x.is_cuda):        # cls:84
             y_hat, _ = self.model(x)                                       # cls:85
             loss = soft_target_cross_entropy(y_hat.squeeze(), y_soft)      # cls:86
+        return self._finish(loss, y_hat)
+
+    def _finish(self, loss, y_hat):
+        """backward, gradient exchange, unscale / clip / optimizer step, zero_grad (cls:87-96)."""
         if self.scaler is not None:
             self.scaler.scale(loss).backward()                             # cls:87
         else:
@@ -201,6 +205,39 @@ class TrainStep:
             self.opt.step()
         self.opt.zero_grad()                                               # cls:96
         return loss.detach(), y_hat.detach()
+
+
+class RegTrainStep(TrainStep):
+    """One iteration of the generative trainer (distributed_trainer_reg.py:71-95): the `generate=True` model returns
+    tokens [B,S,3S]; they are viewed as the image [B,3,S,S] (:78-79), loss = HuberLoss(img, x) + 0.1 * kl_loss
+    (:81,87), then the same scale / clip(1.0) / optimizer step as the classification trainer."""
+
+    def __init__(self, model, optimizer, reducer=None, max_norm=1.0, scaler=None, autocast_dtype=None, kl_weight=0.1):
+        super().__init__(model, optimizer, reducer, max_norm=max_norm, scaler=scaler, autocast_dtype=autocast_dtype)
+        self.kl_weight = kl_weight
+
+    def __call__(self, x, _y=None):
+        S = x.shape[-1]
+        with torch.autocast(device_type="cuda", dtype=self.autocast_dtype or torch.bfloat16,
+                            enabled=self.autocast_dtype is not None and x.is_cuda):        # reg:76
+            y_hat, kl = self.model(x)                                      # reg:77
+            img = y_hat.reshape(-1, S, S, 3).permute(0, 3, 1, 2)           # reg:78-79
+            loss = torch.nn.functional.huber_loss(img, x) + kl * self.kl_weight   # reg:81,87
+        return self._finish(loss, img)
+
+
+def evaluate(model, batches):
+    """Top-1 accuracy over (x, labels) batches in eval mode (CALM_ViT_V2.py:228-239)."""
+    was_training = model.training
+    model.eval()
+    correct = total = 0
+    with torch.no_grad():
+        for x, labels in batches:
+            y_hat, _ = model(x)
+            correct += int((y_hat.reshape(x.shape[0], -1).argmax(dim=1) == labels).sum())
+            total += int(labels.numel())
+    model.train(was_training)
+    return correct / max(total, 1)
 
 
 def make_optimizer(model, lr=3.1e-3, weight_decay=0.02, betas=(0.9, 0.98), capturable=False):

@@ -10,6 +10,7 @@ import calm_vit_dte_amd as calm
 import weights as W
 from emulated_backend import EmulatedBackend
 from helpers import CONFIGS, WEIGHT_SEED, load_golden, load_inventory, rel_err
+from oracle import calm_oracle as O
 
 GOLDEN_CFGS = ["nano48_cls", "nano48_gen", "tiny32_cls", "tiny32_fr"]
 
@@ -123,3 +124,45 @@ def test_fused_optimizer_step_defers_spectral_norm_gradient_and_matches_torch():
     assert not calm.ops.DEFERRED_SN
     worst = max((rel_err(results[1][k], results[0][k]), k) for k in results[0])
     assert worst[0] < 1e-4, worst                          # Adam amplifies fp32 rounding of near-zero gradients
+
+
+def test_generative_trainer_step_and_eval_loop():
+    """trainer.RegTrainStep (distributed_trainer_reg.py:71-95: Huber(img, x) + 0.1*kl on the generate=True model)
+    against the same iteration driven through the CPU oracle, and trainer.evaluate (CALM_ViT_V2.py:228-239)."""
+    from importlib import import_module
+    trainer = import_module("calm_vit_dte_amd.trainer")
+    name = "nano48_gen"
+    g = load_golden(name)
+    cfg = CONFIGS[name]
+    x = torch.from_numpy(W.make_input((2, 3, cfg.seq_length, cfg.seq_length), 2))
+    # oracle iteration
+    P = {k: torch.from_numpy(v) for k, v in W.make_params(O.vit_param_shapes(cfg), WEIGHT_SEED).items()}
+    for k in P:
+        if O.is_buffer(k):
+            P[k] = torch.from_numpy(g["warm/" + k].copy())
+    leaves = [P[k].requires_grad_(True) for k in P if not O.is_buffer(k)]
+    y_o, kl_o = O.vit_forward(P, cfg, x, True, W.NoiseStream(7))
+    img = y_o.reshape(-1, cfg.seq_length, cfg.seq_length, 3).permute(0, 3, 1, 2)
+    loss_o = torch.nn.functional.huber_loss(img, x) + 0.1 * kl_o
+    loss_o.backward()
+    norm_o = torch.nn.utils.clip_grad_norm_(leaves, 1.0)
+    with calm.backend.use_backend(EmulatedBackend()):
+        m = build_model(name, g).train()
+        opt = trainer.FusedClipAdamW(m)
+        step = trainer.RegTrainStep(m, opt, None)
+        calm.ops.set_noise_override(W.NoiseStream(7))
+        try:
+            loss_h, img_h = step(x)
+        finally:
+            calm.ops.set_noise_override(None)
+            opt.close()
+        assert img_h.shape == x.shape
+        assert abs(float(loss_h) - float(loss_o)) < 1e-5 * max(1.0, abs(float(loss_o)))
+        assert abs(float(opt.stats[0]) - float(norm_o)) < 1e-4 * float(norm_o)
+        # eval loop on the classification fixture
+        mc = build_model("nano48_cls", load_golden("nano48_cls"))
+        xs = torch.from_numpy(W.make_input((4, 3, 48, 48), 5))
+        with torch.no_grad():
+            labels = mc.eval()(xs)[0].reshape(4, -1).argmax(dim=1)
+        assert trainer.evaluate(mc, [(xs[:2], labels[:2]), (xs[2:], labels[2:])]) == 1.0
+        assert trainer.evaluate(mc, [(xs, (labels + 1) % 10)]) == 0.0
