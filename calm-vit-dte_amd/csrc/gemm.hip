@@ -41,6 +41,7 @@ struct GemmP {
     int atomic;     // partial results combined with fp32 atomics (split-K / batch-reduce)
     int tiles_m, tiles_n;
     // grouped form: the b0 entries are separate allocations with their own spectral-norm scale
+    int slices_per_batch;          // batched split-K: k-slices per batch entry (0: off)
     int n_group, reduce_group;     // reduce_group: the groups are summed into one C
     const float* Ag[4]; const float* Bg[4]; float* Cg[4]; const float* Sg[4];
 };
@@ -181,7 +182,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
                                               int r, int h, int z, int sgroup) {
     float scale = p.alpha;
     if (p.inv_scale) scale = scale / p.inv_scale[0];
-    const int zc = p.atomic ? 0 : z;
+    const int zc = (p.atomic && !p.slices_per_batch) ? 0 : z;
     const int cb0 = zc / p.batch1, cb1 = zc - cb0 * p.batch1;
     const long coff = cb0 * p.c_b0 + cb1 * p.c_b1;
     float* __restrict__ Cb = p.C + coff;
@@ -299,9 +300,17 @@ __global__ __launch_bounds__(NTHREADS, BN_ == 96 ? CALM_GEMM_WAVES96 : CALM_GEMM
     }
     const int tn = lin % p.tiles_n, tm = lin / p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN_;
-    const int z = blockIdx.y;
-    const int kb_begin = z * p.kb_per_z;
-    const int kb_end = min(kb_begin + p.kb_per_z, p.kb_total);
+    // grid.y: batch entry (plain), k-slice of the concatenated reduction (split-K / reduce_batch), or — batched
+    // split-K, slices_per_batch > 0 — k-slice `z % spb` of batch entry `z / spb` (entry-local reduction range)
+    int z = blockIdx.y;
+    int kb_begin = z * p.kb_per_z;
+    int kb_end = min(kb_begin + p.kb_per_z, p.kb_total);
+    if (p.slices_per_batch) {
+        const int b = z / p.slices_per_batch, sl = z - b * p.slices_per_batch;
+        kb_begin = b * p.kpb + sl * p.kb_per_z;
+        kb_end = min(kb_begin + p.kb_per_z, (b + 1) * p.kpb);
+        z = b;                                   // the epilogue's batch index
+    }
     if (kb_begin >= kb_end && p.atomic) return;
     STAMP_REAL(t_begin);
 #ifdef CALM_GEMM_STAMP
@@ -529,9 +538,17 @@ __global__ __launch_bounds__(NTHREADS, CALM_GEMM_BF16_WAVES) void gemm_bf16c_ker
     }
     const int tn = lin % p.tiles_n, tm = lin / p.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN_;
-    const int z = blockIdx.y;
-    const int kb_begin = z * p.kb_per_z;
-    const int kb_end = min(kb_begin + p.kb_per_z, p.kb_total);
+    // grid.y: batch entry (plain), k-slice of the concatenated reduction (split-K / reduce_batch), or — batched
+    // split-K, slices_per_batch > 0 — k-slice `z % spb` of batch entry `z / spb` (entry-local reduction range)
+    int z = blockIdx.y;
+    int kb_begin = z * p.kb_per_z;
+    int kb_end = min(kb_begin + p.kb_per_z, p.kb_total);
+    if (p.slices_per_batch) {
+        const int b = z / p.slices_per_batch, sl = z - b * p.slices_per_batch;
+        kb_begin = b * p.kpb + sl * p.kb_per_z;
+        kb_end = min(kb_begin + p.kb_per_z, (b + 1) * p.kpb);
+        z = b;                                   // the epilogue's batch index
+    }
     if (kb_begin >= kb_end && p.atomic) return;
 
     f32x16 acc[MT][NT];
@@ -693,7 +710,10 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     const int pad128 = (a->N + 127) / 128 * 128, pad96 = (a->N + 95) / 96 * 96;
     int bn = pad96 < pad128 ? 96 : 128;
     const bool grouped_reduce_unsplit = a->n_group && a->reduce_batch && a->split_k <= 1;
-    const bool k_split = (a->reduce_batch && !grouped_reduce_unsplit) || a->split_k > 1 ||
+    // grouped weight gradients (dW_g = dY_g^T X of the projections that share X): every group gets its own k-slices
+    const bool group_split = a->n_group && !a->reduce_batch && a->split_k == 0 && trivial_epi && a->C_group[0] &&
+                             p.tiles_m * ((a->N + bn - 1) / bn) * batch < 256 && p.kpb >= 64;
+    const bool k_split = group_split || (a->reduce_batch && !grouped_reduce_unsplit) || a->split_k > 1 ||
                          (a->split_k == 0 && batch == 1 && trivial_epi && p.tiles_m * ((a->N + bn - 1) / bn) < 256 &&
                           p.kpb >= 64);
     if (!k_split) {
@@ -711,7 +731,18 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     const int split_slots = bn == 96 ? 256 * CALM_GEMM_WAVES96 : 256 * CALM_GEMM_WAVES;
     int nsplit = 1;
     p.atomic = 0;
-    if (grouped_reduce_unsplit) {
+    p.slices_per_batch = 0;
+    if (group_split) {
+        nsplit = split_slots / (tiles * batch);
+        const int max_split = (p.kpb + 15) / 16;
+        if (nsplit > max_split) nsplit = max_split;
+        if (nsplit < 1) nsplit = 1;
+        p.kb_total = batch * p.kpb;
+        if (nsplit > 1) {
+            p.atomic = 1;
+            p.slices_per_batch = nsplit;
+        }
+    } else if (grouped_reduce_unsplit) {
         p.kb_total = batch * p.kpb;                         // one k-range over all groups, plain epilogue
     } else if (a->reduce_batch) {
         p.atomic = 1;
@@ -731,7 +762,17 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     } else {
         p.kb_total = batch * p.kpb;
     }
-    if (p.atomic) {
+    if (p.slices_per_batch) {
+        p.kb_per_z = (p.kpb + nsplit - 1) / nsplit;
+        if (!a->accumulate) {
+            for (int g = 0; g < a->n_group; ++g) {
+                hipError_t e;
+                if (a->c_rs == a->N) e = hipMemsetAsync(p.Cg[g], 0, sizeof(float) * (size_t)a->M * a->N, s);
+                else e = hipMemset2DAsync(p.Cg[g], sizeof(float) * a->c_rs, 0, sizeof(float) * a->N, a->M, s);
+                if (e != hipSuccess) return (int)e;
+            }
+        }
+    } else if (p.atomic) {
         if (!trivial_epi) return CALM_E_UNSUPP;
         p.kb_per_z = (p.kb_total + nsplit - 1) / nsplit;
         if (!a->accumulate) {
@@ -745,7 +786,7 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     } else {
         p.kb_per_z = p.kpb;   // grid.y == batch
     }
-    const int gy = (p.kb_total + p.kb_per_z - 1) / p.kb_per_z;
+    const int gy = p.slices_per_batch ? batch * p.slices_per_batch : (p.kb_total + p.kb_per_z - 1) / p.kb_per_z;
     if (gy > 65535) return CALM_E_UNSUPP;
     dim3 grid(tiles, gy);
 

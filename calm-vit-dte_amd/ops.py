@@ -258,11 +258,12 @@ class SNLinearGroupFn(Function):
         N, K = ws[0].shape
         M = x2.shape[0]
         dy2 = [_c(d).reshape(-1, N) for d in dys]
+        # weight gradients G_g = dy_g^T x: one grouped launch, every group split over its own k-slices
+        Gs = [torch.empty_like(w) for w in ws]
+        be.gemm(dy2, x2, Gs, N, K, M, (1, N, 0, 0), (1, K, 0, 0), (K, 0, 0), batch=(n, 1))
         grads = []
         for g in range(n):
-            G = torch.empty_like(ws[g])
-            _lin_wgrad(be, dy2[g], x2, G)
-            grads += [_sn_wbwd(be, G, ws[g], us[g], vs[g], sigmas[g])[0], None, None, None]
+            grads += [_sn_wbwd(be, Gs[g], ws[g], us[g], vs[g], sigmas[g])[0], None, None, None]
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)

@@ -383,3 +383,19 @@ def test_gemm_grouped_projections_and_their_input_gradient(hip, emu, n, M, D):
     again = torch.empty_like(dx_hip)
     run(again)
     assert torch.equal(dx_hip, again)                     # unsplit: no atomics
+
+
+@pytest.mark.parametrize("n,T,D", [(3, 8192, 96), (2, 5000, 240), (3, 3000, 52)])
+def test_gemm_grouped_weight_gradients_split_per_group(hip, emu, n, T, D):
+    """dW_g = dY_g^T X for the projections that share X: one grouped launch in which every group is split over its
+    own k-slices (batched split-K, fp32 atomics per group output)."""
+    x = rnd(T, D, seed=1)
+    dys = [rnd(T, D, seed=20 + g) for g in range(n)]
+    G_ref = [torch.zeros(D, D) for _ in range(n)]
+    G_hip = [torch.full((D, D), 9.0).cuda() for _ in range(n)]          # must be overwritten
+    args = (D, D, T, (1, D, 0, 0), (1, D, 0, 0), (D, 0, 0))
+    emu.gemm(dys, x, G_ref, *args, batch=(n, 1))
+    hip.gemm([d.cuda() for d in dys], x.cuda(), G_hip, *args, batch=(n, 1))
+    for g in range(n):
+        assert rel_err(G_hip[g], G_ref[g]) < TOL
+        assert rel_err(G_hip[g], dys[g].T @ x) < TOL
