@@ -86,6 +86,50 @@ __device__ __forceinline__ long long stamp_real() {      // 100 MHz, one counter
 #define STAMP_REAL(var)
 #endif
 
+// 16-byte staging with a per-thread cursor: the row part of every address is computed once per (tile, batch entry),
+// the k-loop only advances the pointers.  Rows past the tile (edge tiles, and rows 96..127 of the 128-row thread map
+// on a 96-row B tile) are CLAMPED to the tile's last row instead of masked: they only feed output rows / columns
+// that are never stored, so the loads stay unconditional (no exec masking, no zero fill).  Only a partial last
+// k-block (K % BK != 0) takes the masked form.
+template <bool KC, int ROWS>
+struct OperandCursor {
+    const float* ptr[NREG / 4];
+    long step;
+    __device__ __forceinline__ void init(const float* base, long rs, long cs, int row0, int nrows_all, int k0) {
+        const int tid = threadIdx.x;
+        const int last = min(nrows_all, row0 + ROWS) - 1;
+        if constexpr (KC) {
+            constexpr int KQ = BK / 4, RPP = NTHREADS / KQ;
+#pragma unroll
+            for (int i = 0; i < NREG / 4; ++i)
+                ptr[i] = base + (long)min(row0 + (tid / KQ) + RPP * i, last) * rs + k0 + 4 * (tid % KQ);
+            step = BK;
+        } else {
+            const int row = min(row0 + 4 * (tid & 31), last & ~3);      // rows come in aligned groups of 4 (M % 4 == 0)
+#pragma unroll
+            for (int i = 0; i < NREG / 4; ++i) ptr[i] = base + (long)(k0 + (tid >> 5) + 8 * i) * cs + row;
+            step = BK * cs;
+        }
+    }
+    // k_left = K - k0 (> 0); full k-blocks take the unconditional form
+    __device__ __forceinline__ void load(int k_left, float (&reg)[NREG]) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NREG / 4; ++i) {
+            f32x4 v;
+            if (k_left >= BK) {
+                v = *reinterpret_cast<const f32x4*>(ptr[i]);
+            } else {
+                const int k = KC ? 4 * (tid % (BK / 4)) : (tid >> 5) + 8 * i;
+                v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (k < k_left) v = *reinterpret_cast<const f32x4*>(ptr[i]);
+            }
+            ptr[i] += step;
+            reg[4 * i + 0] = v[0]; reg[4 * i + 1] = v[1]; reg[4 * i + 2] = v[2]; reg[4 * i + 3] = v[3];
+        }
+    }
+};
+
 template <bool KC, int VEC, int ROWS>
 __device__ __forceinline__ void load_operand(const float* __restrict__ base, long rs, long cs, int row0,
                                              int nrows_all, int k0, int K, float (&reg)[NREG]) {
@@ -327,21 +371,28 @@ __global__ __launch_bounds__(NTHREADS, BN_ == 96 ? CALM_GEMM_WAVES96 : CALM_GEMM
 
     float ra[NREG], rb[NREG];
 
+    OperandCursor<AKC, BM> ca;
+    OperandCursor<BKC, BN_> cb;
+    int cur_b = -1;                       // batch entry the cursors point into
     auto fetch = [&](int kb) {
-        const int b = kb / p.kpb;
-#if (CALM_GEMM_ABLATE & 16)
-        const int k0 = 0;
-#else
+        const int b = p.kb_total == p.kpb ? 0 : kb / p.kpb;          // single-entry launches skip the divisions
         const int k0 = (kb - b * p.kpb) * BK;
-#endif
-        const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
-#if (CALM_GEMM_ABLATE & 32)
-        if (kb == kb_begin)
-#endif
-        load_operand<AKC, VEC, BM>(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0,
-                                   p.M, k0, p.K, ra);
-        load_operand<BKC, VEC, BN_>(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0,
-                                    p.N, k0, p.K, rb);
+        if constexpr (VEC == 4) {
+            if (b != cur_b) {                                         // wave-uniform: first fetch, or a batch boundary
+                const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
+                ca.init(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, k0);
+                cb.init(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
+                cur_b = b;
+            }
+            ca.load(p.K - k0, ra);
+            cb.load(p.K - k0, rb);
+        } else {
+            const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
+            load_operand<AKC, VEC, BM>(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0,
+                                       p.M, k0, p.K, ra);
+            load_operand<BKC, VEC, BN_>(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs,
+                                        n0, p.N, k0, p.K, rb);
+        }
     };
 
     int buf = 0;
