@@ -526,6 +526,44 @@ __device__ __forceinline__ void c_load(const float* __restrict__ base, long rs, 
     }
 }
 
+// cursor form of c_load (see OperandCursor): row addresses once per (tile, batch entry), clamped edge rows,
+// unconditional 16-byte loads for full k-blocks
+template <bool KC, int ROWS>
+struct CCursor {
+    const float* ptr[4];
+    long step;
+    __device__ __forceinline__ void init(const float* base, long rs, long cs, int row0, int nrows_all, int k0) {
+        const int tid = threadIdx.x;
+        const int last = min(nrows_all, row0 + ROWS) - 1;
+        if constexpr (KC) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ptr[i] = base + (long)min(row0 + (tid >> 3) + 32 * i, last) * rs + k0 + 4 * (tid & 7);
+            step = CK;
+        } else {
+            const int row = min(row0 + 4 * (tid & 31), last & ~3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ptr[j] = base + (long)(k0 + 4 * (tid >> 5) + j) * cs + row;
+            step = CK * cs;
+        }
+    }
+    __device__ __forceinline__ void load(int k_left, f32x4 (&reg)[4]) {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v;
+            if (k_left >= CK) {
+                v = *reinterpret_cast<const f32x4*>(ptr[i]);
+            } else {
+                const int k = KC ? 4 * (tid & 7) : 4 * (tid >> 5) + i;
+                v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (k < k_left) v = *reinterpret_cast<const f32x4*>(ptr[i]);
+            }
+            ptr[i] += step;
+            reg[i] = v;
+        }
+    }
+};
+
 template <int NPASS>
 __device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
 #pragma unroll
@@ -611,12 +649,20 @@ __global__ __launch_bounds__(NTHREADS, CALM_GEMM_BF16_WAVES) void gemm_bf16c_ker
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     f32x4 ra[4], rb[4];
+    CCursor<AKC, BM> ca;
+    CCursor<BKC, BN_> cb;
+    int cur_b = -1;
     auto fetch = [&](int kb) {
-        const int b = kb / p.kpb;
+        const int b = p.kb_total == p.kpb ? 0 : kb / p.kpb;
         const int k0 = (kb - b * p.kpb) * CK;
-        const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
-        c_load<AKC, BM>(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, k0, p.K, ra);
-        c_load<BKC, BN_>(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0, p.K, rb);
+        if (b != cur_b) {
+            const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
+            ca.init(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, k0);
+            cb.init(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
+            cur_b = b;
+        }
+        ca.load(p.K - k0, ra);
+        cb.load(p.K - k0, rb);
     };
     auto stash = [&](int st) {
         c_store<AKC, NPASS>(lds[st][0][0], lds[st][0][NPL - 1], ra);
