@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""Timing experiment (needs a library built with -DCALM_GEMM_STAMP): where does a workgroup's time go inside the fp32
+"""Timing experiment.  Needs a library with the in-kernel phase stamps, which live in the history, not in the product
+source: build calm-vit-dte_amd/csrc/gemm.hip of commit d96fccc…a953380 with -DCALM_GEMM_STAMP (and -DCALM_GEMM_ABLATE=n
+for the main-loop ablations) and point CALM_VIT_LIB at it.
+ where does a workgroup's time go inside the fp32
 GEMM kernel?  Per-phase s_memtime sums of wave 0 of every workgroup, plus the per-CU timeline (how many co-resident
 workgroups are inside their k-loop at any moment).
    CALM_VIT_LIB=$PWD/ab/lib_stamp.so python3 scripts/gemm_stamps.py [M N K]"""
