@@ -83,6 +83,7 @@ SIGNATURES = {
     "calm_sn_weight_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p, _p]),
     "calm_optim_chunk_elems": (_i32, []),
     "calm_optim_step": (_i32, [_p, _i32, _p, _i32, _p, C.POINTER(OptimHparams), _p, _p, _p]),
+    "calm_collate_mix": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p]),
     "calm_image_to_rows": (_i32, [_p, _p, _i32, _i32, _p]),
     "calm_rows_to_image": (_i32, [_p, _p, _i32, _i32, _p]),
     "calm_grid_transpose": (_i32, [_p, _p, _i32, _i32, _p]),

@@ -152,6 +152,18 @@ class HipBackend:
         g.dtype = PRECISIONS[effective_precision()]
         _lib.check(self.lib.calm_gemm(C.byref(g), _stream()), "calm_gemm")
 
+    # ---- device-side collate -------------------------------------------------------------
+    def collate_mix(self, img_u8, flip, out, mode, lam, box, mean, std):
+        """img_u8 [B,3,H,W] uint8, flip [B] uint8 or None, out [B,3,H,W] fp32; mode 0/1/2 = none/MixUp/CutMix."""
+        if not img_u8.is_cuda or img_u8.dtype != torch.uint8 or not img_u8.is_contiguous():
+            raise TypeError("collate_mix expects a contiguous uint8 CUDA image batch")
+        B, _, H, W = img_u8.shape
+        cbox = (C.c_int32 * 4)(*box) if box is not None else None
+        cm, cs = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+        fp = flip.data_ptr() if flip is not None else None
+        _lib.check(self.lib.calm_collate_mix(img_u8.data_ptr(), fp, _ptr(out), B, H, W, mode, float(lam), cbox, cm, cs,
+                                             _stream()), "calm_collate_mix")
+
     # ---- optimizer-side step ------------------------------------------------------------
     def optim_plan(self, records):
         """records: one dict per parameter — param, exp_avg, exp_avg_sq, sn (None or (u, v, sigma, rows, cols))."""

@@ -226,6 +226,47 @@ class RegTrainStep(TrainStep):
         return self._finish(loss, img)
 
 
+class DeviceCollate:
+    """The batch-level part of the reference's input pipeline on the device:
+    ToDtype(scale=True) + Normalize + RandomHorizontalFlip + RandomChoice([CutMix(alpha=1.0), MixUp(alpha=0.8)])
+    with 1000-way soft labels (distributed_trainer_cls.py:58-61,128-139, torchvision.transforms.v2 semantics), one kernel
+    pass over the uint8 batch (calm_collate_mix).  The decode / resize / colour augmentations stay with the loader.
+    torchvision is not installed in the build image, so the semantics are restated from its documentation."""
+
+    MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+
+    def __init__(self, num_classes=1000, cutmix_alpha=1.0, mixup_alpha=0.8, flip_p=0.5, seed=None):
+        self.num_classes, self.cutmix_alpha, self.mixup_alpha, self.flip_p = num_classes, cutmix_alpha, mixup_alpha, flip_p
+        self.gen = torch.Generator().manual_seed(seed) if seed is not None else None
+
+    def draw(self, B, H, W):
+        """(mode, lam, box, flips): the random decisions of one batch (host side, tiny)."""
+        u = lambda: float(torch.rand((), generator=self.gen))
+        mode = 2 if u() < 0.5 else 1                                        # RandomChoice([cut_mix, mix_up])
+        alpha = self.cutmix_alpha if mode == 2 else self.mixup_alpha
+        lam = float(torch._sample_dirichlet(torch.tensor([alpha, alpha]), generator=self.gen)[0])   # Beta(a, a)
+        box = None
+        if mode == 2:
+            rx, ry = int(u() * W), int(u() * H)
+            r = 0.5 * (1.0 - lam) ** 0.5
+            hw, hh = int(r * W), int(r * H)
+            x1, y1, x2, y2 = max(rx - hw, 0), max(ry - hh, 0), min(rx + hw, W), min(ry + hh, H)
+            box = (y1, y2, x1, x2)
+            lam = 1.0 - (x2 - x1) * (y2 - y1) / float(W * H)
+        flips = (torch.rand(B, generator=self.gen) < self.flip_p).to(torch.uint8)
+        return mode, lam, box, flips
+
+    def __call__(self, img_u8, labels, decisions=None):
+        from .backend import get_backend
+        B, _, H, W = img_u8.shape
+        mode, lam, box, flips = decisions if decisions is not None else self.draw(B, H, W)
+        out = torch.empty(img_u8.shape, dtype=torch.float32, device=img_u8.device)
+        get_backend().collate_mix(img_u8, flips.to(img_u8.device), out, mode, lam, box, self.MEAN, self.STD)
+        onehot = torch.nn.functional.one_hot(labels, self.num_classes).to(torch.float32)
+        y = onehot * lam + onehot.roll(1, 0) * (1.0 - lam)
+        return out, y
+
+
 def evaluate(model, batches):
     """Top-1 accuracy over (x, labels) batches in eval mode (CALM_ViT_V2.py:228-239)."""
     was_training = model.training

@@ -256,6 +256,17 @@ int calm_optim_step(const calm_optim_tensor* tensors_dev, int32_t n_tensors, con
                     const float* grad_scale /* device scalar or NULL */, float* stats_out, void* stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Device-side batch collate feeding the path: uint8 images [B,3,H,W] -> normalised fp32 batch with
+ * per-sample horizontal flip (flip[b] != 0; NULL = none) and the batch-level CutMix / MixUp of
+ * distributed_trainer_cls.py:58-61 (torchvision.transforms.v2 semantics: partner = the batch rolled by one):
+ *   mode 0 none | 1 MixUp: lam*x + (1-lam)*x_rolled | 2 CutMix: box = {y1,y2,x1,x2} (host ints) taken from x_rolled
+ * mean/std: host float[3] (Normalize after ToDtype(scale=True), cls:137-139).  The random draws (lam ~ Beta, box,
+ * flips) and the soft labels lam*onehot(y) + (1-lam)*onehot(y_rolled) are the caller's.
+ * ------------------------------------------------------------------------------------- */
+int calm_collate_mix(const uint8_t* img_u8, const uint8_t* flip, float* out, int32_t B, int32_t H, int32_t W,
+                     int32_t mode, float lam, const int32_t* box, const float* mean, const float* std, void* stream);
+
+/* ---------------------------------------------------------------------------------------
  * Tokenisation (bit-exact index work).
  * image_to_rows : rows[b,i,3j+c] = img[b,c,i,j]           (Vi_Tools:389-391); rows_to_image inverse.
  * grid_transpose: out[b,j,3i+c]  = in[b,i,3j+c]           (Vi_Tools:394-395,397-398; self-inverse)

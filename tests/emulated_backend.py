@@ -112,6 +112,20 @@ class EmulatedBackend:
             z = z + Cv
         Cv.copy_(z)
 
+    def collate_mix(self, img_u8, flip, out, mode, lam, box, mean, std):
+        x = img_u8.float() / 255.0
+        if flip is not None:
+            x = torch.where(flip.bool()[:, None, None, None], x.flip(-1), x)
+        x = (x - torch.tensor(mean)[None, :, None, None]) / torch.tensor(std)[None, :, None, None]
+        xr = x.roll(1, 0)
+        if mode == 1:
+            x = x * lam + xr * (1.0 - lam)
+        elif mode == 2:
+            y1, y2, x1, x2 = box
+            x = x.clone()
+            x[..., y1:y2, x1:x2] = xr[..., y1:y2, x1:x2]
+        out.copy_(x)
+
     def optim_plan(self, records):
         return records
 

@@ -166,3 +166,29 @@ def test_generative_trainer_step_and_eval_loop():
             labels = mc.eval()(xs)[0].reshape(4, -1).argmax(dim=1)
         assert trainer.evaluate(mc, [(xs[:2], labels[:2]), (xs[2:], labels[2:])]) == 1.0
         assert trainer.evaluate(mc, [(xs, (labels + 1) % 10)]) == 0.0
+
+
+def test_device_collate_soft_labels_and_decisions():
+    """trainer.DeviceCollate: CutMix's lam is re-derived from the clipped box, labels are lam*onehot + (1-lam)*rolled
+    (rows sum to 1), MixUp / CutMix are both drawn, and the image pass goes through the backend."""
+    from importlib import import_module
+    trainer = import_module("calm_vit_dte_amd.trainer")
+    dc = trainer.DeviceCollate(num_classes=10, seed=3)
+    img = torch.randint(0, 256, (6, 3, 32, 32), dtype=torch.uint8)
+    labels = torch.tensor([0, 1, 2, 3, 4, 5])
+    modes = set()
+    with calm.backend.use_backend(EmulatedBackend()):
+        for _ in range(12):
+            d = dc.draw(6, 32, 32)
+            mode, lam, box, flips = d
+            modes.add(mode)
+            assert 0.0 <= lam <= 1.0 and flips.shape == (6,)
+            if mode == 2:
+                y1, y2, x1, x2 = box
+                assert 0 <= y1 <= y2 <= 32 and 0 <= x1 <= x2 <= 32
+                assert abs(lam - (1 - (y2 - y1) * (x2 - x1) / 1024.0)) < 1e-6
+            x, y = dc(img, labels, decisions=d)
+            assert x.shape == (6, 3, 32, 32) and x.dtype == torch.float32
+            assert torch.allclose(y.sum(dim=1), torch.ones(6), atol=1e-6)
+            assert abs(float(y[1, 1]) - lam) < 1e-6 and abs(float(y[1, 0]) - (1 - lam)) < 1e-6
+    assert modes == {1, 2}

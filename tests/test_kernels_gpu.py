@@ -399,3 +399,24 @@ def test_gemm_grouped_weight_gradients_split_per_group(hip, emu, n, T, D):
     for g in range(n):
         assert rel_err(G_hip[g], G_ref[g]) < TOL
         assert rel_err(G_hip[g], dys[g].T @ x) < TOL
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_device_collate_mixup_cutmix_normalize_flip(hip, emu, mode):
+    """calm_collate_mix against the torch restatement of ToDtype(scale) + Normalize + flip + MixUp / CutMix
+    (distributed_trainer_cls.py:58-61,128-139): uint8 arithmetic in fp32 is exact up to rounding of the normalise."""
+    B, H, W = 5, 40, 56
+    g = torch.Generator().manual_seed(mode)
+    img = torch.randint(0, 256, (B, 3, H, W), generator=g, dtype=torch.uint8)
+    flip = (torch.rand(B, generator=g) < 0.5).to(torch.uint8)
+    box = (7, 29, 10, 41)
+    mean, std = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
+    ref, out = torch.empty(B, 3, H, W), torch.empty(B, 3, H, W).cuda()
+    emu.collate_mix(img, flip, ref, mode, 0.3, box, mean, std)
+    hip.collate_mix(img.cuda(), flip.cuda(), out, mode, 0.3, box, mean, std)
+    assert rel_err(out, ref) < 1e-6
+    if mode == 2:          # outside the box nothing is mixed, inside it is the rolled partner
+        plain = torch.empty(B, 3, H, W).cuda()
+        hip.collate_mix(img.cuda(), flip.cuda(), plain, 0, 1.0, None, mean, std)
+        assert torch.equal(out[..., :7, :], plain[..., :7, :])
+        assert torch.equal(out[..., 7:29, 10:41], plain.roll(1, 0)[..., 7:29, 10:41])
