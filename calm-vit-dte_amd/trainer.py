@@ -189,11 +189,24 @@ class TrainStep:
         if self.reducer is not None:
             self.reducer.finish()
         if isinstance(self.opt, FusedClipAdamW):                           # cls:88-96 in three launches
-            if self.scaler is not None:
-                raise NotImplementedError("FusedClipAdamW: pass scaler=None (gradients are fp32; bf16 autocast "
-                                          "needs no loss scaling) or call opt.step(grad_scale=...) yourself")
             self.opt.max_norm = self.max_norm
-            self.opt.step()
+            if self.scaler is not None and self.scaler.is_enabled():
+                # GradScaler semantics on device, no host sync: unscale + inf check + skip-on-inf happen inside
+                # calm_optim_step; the scale then backs off (x backoff) on inf/NaN or grows (x growth) after
+                # growth_interval clean steps, exactly as scaler.step() / scaler.update() would do it
+                sc = self.scaler
+                stats = self.opt.step(grad_scale=sc._scale)
+                if not hasattr(self, "_clean_steps"):
+                    self._clean_steps = torch.zeros((), dtype=torch.int32, device=stats.device)
+                bad = stats[1] > 0
+                self._clean_steps = torch.where(bad, torch.zeros_like(self._clean_steps), self._clean_steps + 1)
+                grow = self._clean_steps >= sc.get_growth_interval()
+                new_scale = torch.where(bad, sc._scale * sc.get_backoff_factor(),
+                                        torch.where(grow, sc._scale * sc.get_growth_factor(), sc._scale))
+                self._clean_steps = torch.where(grow, torch.zeros_like(self._clean_steps), self._clean_steps)
+                sc.update(new_scale.detach())
+            else:
+                self.opt.step()
             return loss.detach(), y_hat.detach()
         if self.scaler is not None:
             self.scaler.unscale_(self.opt)                                 # cls:88

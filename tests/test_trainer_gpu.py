@@ -211,3 +211,45 @@ def test_fused_optimizer_gradient_norm_and_skip_on_nonfinite():
                 assert torch.equal(v, snap[k]), k
     finally:
         opt.close()
+
+
+def test_fused_optimizer_with_grad_scaler_matches_torch_amp_step():
+    """The reference's scaler sequence (cls:87-95: scaler.scale(loss).backward(), unscale_, clip, scaler.step,
+    scaler.update) with the fused optimizer-side step: same parameters as the torch sequence after a step, the scale
+    backs off when a gradient is non-finite and the update is skipped."""
+    name = "tiny32_cls"
+    g = load_golden(name)
+    cfg, x, y = _batch(name, bs=4)
+    x, y = x.cuda(), y.cuda()
+    outs = []
+    for fused in (False, True):
+        m = build_model(name, g, "cuda").train()
+        opt = trainer.FusedClipAdamW(m) if fused else trainer.make_optimizer(m)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        step = trainer.TrainStep(m, opt, None, scaler=scaler)     # fp32 pipe: the comparison is about the scaler logic
+        try:
+            step(x, y)
+            outs.append(({k: v.clone() for k, v in m.state_dict().items()}, float(scaler.get_scale())))
+            if fused:
+                # poison one gradient through a huge loss scale: inf -> skipped step, scale halves
+                before = {k: v.clone() for k, v in m.state_dict().items() if not O.is_buffer(k)}
+                scaler.update(float("inf"))
+                step(x, y)
+                assert float(opt.stats[1]) == 1.0
+                for k, v in m.state_dict().items():
+                    if k in before:
+                        assert torch.equal(v, before[k]), k
+        finally:
+            if fused:
+                opt.close()
+    (sd_t, sc_t), (sd_f, sc_f) = outs
+    assert sc_t == sc_f == 1024.0
+    start = {k: v for k, v in build_model(name, g, "cuda").state_dict().items()}
+    bad = tot = 0
+    for k in sd_t:
+        if O.is_buffer(k):
+            continue
+        d_t, d_f = sd_t[k] - start[k], sd_f[k] - start[k]
+        bad += int(((d_f - d_t).abs() > 1e-3 * 3.1e-3 + 1e-7).sum())
+        tot += d_t.numel()
+    assert bad <= 1e-3 * tot, (bad, tot)
