@@ -253,3 +253,30 @@ def test_fused_optimizer_with_grad_scaler_matches_torch_amp_step():
         bad += int(((d_f - d_t).abs() > 1e-3 * 3.1e-3 + 1e-7).sum())
         tot += d_t.numel()
     assert bad <= 1e-3 * tot, (bad, tot)
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_rank_path_rehearsed_on_one_gpu():
+    """The N>1 launch contract of bench.py (torch.distributed.run, env:// rendezvous on 127.0.0.1, parameter broadcast,
+    bucketed gradient all-reduce from autograd hooks, fused optimizer-side step on un-corrected spectral-norm
+    gradients, barrier + MAX-over-ranks timing, one JSON line from rank 0) with two ranks sharing cuda:0 and gloo as
+    the transport (RCCL needs two devices; the driver's 8-GPU run uses the same code with backend nccl)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, CALM_DIST_BACKEND="gloo", CALM_LOCAL_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "nano48",
+           "--batch", "8", "--steps", "2", "--warmup", "1", "--prof-steps", "1"]
+    out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=500)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["roofline"]["bound"] == "mfma" and "cpu_baseline" not in d
