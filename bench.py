@@ -287,6 +287,7 @@ def main():
                        "optimizer": "torch clip_grad_norm_ + AdamW" if (args.torch_optim or args.graph)
                        else "calm_optim_step (norm + clip + AdamW + spectral-norm grad correction, 3 launches)"},
             "model_tflops": round(value * wl["gflop_img"] / 1e3, 2),
+            "hbm_peak_gib": round(torch.cuda.max_memory_allocated(device) / 2**30, 1),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
