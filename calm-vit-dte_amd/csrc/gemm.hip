@@ -540,7 +540,7 @@ __device__ __forceinline__ bf16x8 c_frag(const __bf16* __restrict__ plane, int r
 }
 
 template <bool AKC, bool BKC, int NPASS, int BN_>
-__global__ __launch_bounds__(NTHREADS, CALM_GEMM_BF16_WAVES) void gemm_bf16c_kernel(const GemmP p) {
+__global__ __launch_bounds__(NTHREADS, NPASS == 3 ? 2 : CALM_GEMM_BF16_WAVES) void gemm_bf16c_kernel(const GemmP p) {
     constexpr int WN = BN_ == 128 ? 2 : 1;
     constexpr int MT = BN_ == 128 ? 2 : 1;
     constexpr int NT = BN_ / (WN * 32);
