@@ -4,7 +4,7 @@ the MI355X through stock PyTorch-ROCm eager kernels (rocBLAS/hipBLASLt GEMMs, AT
 batch, same step (fwd + soft-target CE + bwd + clip + AdamW).  Answers "what would the reference's eager code
 get on this GPU".  usage: eager_gpu_baseline.py [--batch 256] [--autocast]"""
 import argparse, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
     sys.path.insert(0, p)
 import numpy as np
