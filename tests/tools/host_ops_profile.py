@@ -2,7 +2,7 @@
 """Which host-side call sites issue the small aten fill / copy / add launches of one training step?
 (torch profiler with Python stacks on the Nano-48 model: the host code path is the same for every configuration)"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
     sys.path.insert(0, p)
 from collections import Counter
