@@ -145,7 +145,7 @@ def pmc_traffic(kernel_prefix):
             "source": os.path.relpath(files[-1], ROOT)}
 
 
-def cpu_baseline(wl, budget_s=25.0):
+def cpu_baseline(wl, budget_s=15.0):
     """CPU oracle (port of the reference path) fwd+bwd+AdamW on a bounded sample of the workload."""
     from oracle import calm_oracle as O
     import weights as W
@@ -172,7 +172,7 @@ def cpu_baseline(wl, budget_s=25.0):
 
     step()                                           # warm-up (also converges nothing: timing only)
     times, t_start = [], time.perf_counter()
-    while len(times) < 5 and (time.perf_counter() - t_start) < budget_s:
+    while len(times) < 24 and (time.perf_counter() - t_start) < budget_s:      # about 10-25 s of CPU work
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
