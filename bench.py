@@ -268,10 +268,15 @@ def main():
             roofline = {"bound": "mfma", "kernel": klabel,
                         "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                         "frac": round(achieved / peak, 4),
-                        "traffic": pmc_traffic("gemm_f32_kernel" if args.precision == "fp32" else "gemm_bf16c_kernel"),
+                        "traffic": None,
                         "launches_per_step": n // args.prof_steps, "avg_launch_us": round(1e3 * ms / n, 2),
                         "gemm_ms_per_step": round(ms / args.prof_steps, 2),
                         "algorithmic_gflop_per_step": round(flops / args.prof_steps / 1e9, 1)}
+            # HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate passes) from the committed summary
+            detail = pmc_traffic("gemm_f32_kernel" if args.precision == "fp32" else "gemm_bf16c_kernel")
+            if detail is not None:
+                roofline["traffic"] = detail["hbm_bytes_per_launch"]
+                roofline["traffic_detail"] = detail
     if world > 1:
         dist.barrier()
 
