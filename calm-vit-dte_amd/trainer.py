@@ -18,6 +18,7 @@ The model also works under stock `torch.nn.parallel.DistributedDataParallel` (th
 reference's train() does with it); the reducer here is the MI355X-tuned equivalent.
 """
 import os
+import weakref
 
 import torch
 import torch.distributed as dist
@@ -338,10 +339,13 @@ class FusedClipAdamW:
         self._plan = self.be.optim_plan(records)
         ops.DEFERRED_SN.update(self._deferred)
         self._ops = ops
+        # an optimizer that is dropped without close() must not leave its layers deferred (their backward would hand
+        # out un-corrected gradients with nobody left to correct them)
+        self._finalizer = weakref.finalize(self, ops.DEFERRED_SN.difference_update, tuple(self._deferred))
         self.stats = torch.zeros(2, dtype=torch.float32, device=self.params[0].device)   # [grad norm, found_inf]
 
     def close(self):
-        self._ops.DEFERRED_SN.difference_update(self._deferred)
+        self._finalizer()
         self._deferred = []
 
     @torch.no_grad()
