@@ -366,8 +366,12 @@ __global__ __launch_bounds__(NTHREADS, BN_ == 96 ? CALM_GEMM_WAVES96 : CALM_GEMM
                                         n0, p.N, k0, p.K, rb);
         }
     };
-    // the 8 k-pairs of one staged k-block: 1 (2) A and 3 (2) B fragments per 3 (4) MFMAs
+    // the 8 k-pairs of one staged k-block: 1 (2) A and 3 (2) B fragments per 3 (4) MFMAs.  A wave whose rows all lie
+    // past M (edge tile of a short M: the 40- and 176-row sequence-axis products) stages and synchronises but
+    // issues no MFMAs: its accumulators are never stored.
+    const bool wave_live = m0 + wm * (32 * MT) < p.M;
     auto multiply = [&](int buf) {
+        if (!wave_live) return;
 #pragma unroll
         for (int s = 0; s < BK / 2; ++s) {
             const int kk = 2 * s + h;

@@ -56,4 +56,9 @@ x, w, res, y = g(57344, 672), g(672, 672), g(57344, 672), g(57344, 672)
 ls = g(672)
 t = t_med(lambda: be.gemm(x, w, y, 57344, 672, 672, (672, 1, 0, 0), (672, 1, 0, 0), (672, 0, 0), col_scale=ls, residual=res, r=(672, 0, 0), split_k=1))
 print(f"out_proj (ls+residual) 57344x672x672: {t:7.3f} ms {2.0*57344*672*672/1e9/t:6.1f} TF"); tot += t
+# short-M sequence-axis products (per image): M = 40 / 176 rows in 128-row tiles
+for (Ms, Ns, Ks) in ((40, 528, 176), (176, 528, 176), (176, 672, 224)):
+    a_, b_, c_ = g(256, Ms, Ks), g(256, Ks, Ns), g(256, Ms, Ns)
+    t = t_med(lambda: be.gemm(a_, b_, c_, Ms, Ns, Ks, (Ks, 1, Ms * Ks, 0), (1, Ns, Ks * Ns, 0), (Ns, Ms * Ns, 0), batch=(256, 1), split_k=1))
+    print(f"per-image {Ms}x{Ns}x{Ks} x256: {t:7.3f} ms {2.0*Ms*Ns*Ks*256/1e9/t:6.1f} TF"); tot += t
 print(f"sum {tot:.3f} ms")
