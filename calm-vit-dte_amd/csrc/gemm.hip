@@ -195,6 +195,16 @@ __device__ __forceinline__ void store_operand(float (*T)[LD], const float (&reg)
     }
 }
 
+// compile-time walk over the MT x NT accumulator tiles of a wave (indices stay constants: with 2x3 tiles the
+// optimiser no longer unrolls a runtime double loop of this size and the accumulators would end up in scratch)
+template <int IDX, int MT, int NT, class F>
+__device__ __forceinline__ void for_each_subtile(F&& f, f32x16 (&acc)[MT][NT]) {
+    if constexpr (IDX < MT * NT) {
+        f(IDX / NT, IDX % NT, acc[IDX / NT][IDX % NT]);
+        for_each_subtile<IDX + 1, MT, NT>(f, acc);
+    }
+}
+
 // Shared epilogue: acc (32x32 MFMA C layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) ->
 // scale, bias, optional pre-activation store, GELU / GELU', LayerScale, residual, accumulate or atomics.
 template <int MT, int NT>
@@ -215,12 +225,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
     const float* __restrict__ Xb = p.aux ? p.aux + coff : nullptr;
     const float* __restrict__ Rb = p.residual ? p.residual + cb0 * p.r_b0 + cb1 * p.r_b1 : nullptr;
 
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
+    for_each_subtile<0, MT, NT>([&](int i, int j, const f32x16& a) {
+        {
             const int col = n0 + wn * (32 * NT) + 32 * j + r;
-            if (col >= p.N) continue;
+            if (col >= p.N) return;
             const float bj = p.bias ? p.bias[col] : 0.f;
             const float sj = p.col_scale ? p.col_scale[col] : 1.f;
             const int row0 = m0 + wm * (32 * MT) + 32 * i + 4 * h;
@@ -228,16 +236,16 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = row0 + (e & 3) + 8 * (e >> 2);
-                    if (row < p.M) atomicAdd(Cb + (long)row * p.c_rs + col, acc[i][j][e] * scale);
+                    if (row < p.M) atomicAdd(Cb + (long)row * p.c_rs + col, a[e] * scale);
                 }
-                continue;
+                return;
             }
             // Each extra operand (aux for GELU', residual, old C) is fetched as 16 independent loads into one
             // temporary (rows past M clamped to row 0) and folded into the accumulator in place, one operand at a
             // time: loads stay in flight together without holding three 16-register arrays live.
             float v[16], t[16];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = acc[i][j][e] * scale + bj;
+            for (int e = 0; e < 16; ++e) v[e] = a[e] * scale + bj;
             if (Pb) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
@@ -283,7 +291,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
                 if (row < p.M) Cb[(long)row * p.c_rs + col] = v[e];
             }
         }
-    }
+    }, acc);
 }
 
 template <bool AKC, bool BKC, int VEC, int BN_>
