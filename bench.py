@@ -196,6 +196,9 @@ def main():
     ap.add_argument("--torch-optim", action="store_true",
                     help="clip_grad_norm_ + torch.optim.AdamW(fused) instead of the library's 3-launch optimizer-side "
                          "step (calm_optim_step, which also folds in the spectral-norm gradient correction)")
+    ap.add_argument("--autocast", action="store_true",
+                    help="the reference trainer's call pattern (cls:84-95): forward under torch.autocast(bfloat16), "
+                         "loss scaled by a torch GradScaler — the GEMMs then run on the bf16 pipe as with --precision bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-report", default="", help="write a per-shape GEMM table (csv) from the profiled steps")
     args = ap.parse_args()
@@ -214,7 +217,7 @@ def main():
     batch = args.batch or wl["batch"]
     S, classes = wl["kw"]["seq_length"], wl["kw"]["out_features"]
 
-    calm.backend.set_matmul_precision(args.precision)
+    calm.backend.set_matmul_precision("fp32" if args.autocast else args.precision)
     model = build_model(calm, wl["kw"], device).train()
     trainer.sync_module_states(model)
     x, y = synthetic_batch(batch, S, classes, seed=rank, device=device)     # resident in HBM before timing
@@ -227,7 +230,12 @@ def main():
     else:
         opt = trainer.make_optimizer(model) if args.torch_optim else trainer.FusedClipAdamW(model)
         reducer = trainer.BucketedGradReducer(model) if world > 1 else None
-        step = trainer.TrainStep(model, opt, reducer)
+        if args.autocast:
+            args.precision = "bf16"                         # what the autocast region selects; labels the JSON line
+            step = trainer.TrainStep(model, opt, reducer, scaler=torch.amp.GradScaler("cuda"),
+                                     autocast_dtype=torch.bfloat16)
+        else:
+            step = trainer.TrainStep(model, opt, reducer)
 
     def sync():
         if world > 1:
