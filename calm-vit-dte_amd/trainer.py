@@ -250,24 +250,25 @@ class DeviceCollate:
     MEAN, STD = (0.485, 0.456, 0.406), (0.229, 0.224, 0.225)
 
     def __init__(self, num_classes=1000, cutmix_alpha=1.0, mixup_alpha=0.8, flip_p=0.5, seed=None):
+        import numpy as np
         self.num_classes, self.cutmix_alpha, self.mixup_alpha, self.flip_p = num_classes, cutmix_alpha, mixup_alpha, flip_p
-        self.gen = torch.Generator().manual_seed(seed) if seed is not None else None
+        self.rng = np.random.default_rng(seed)
 
     def draw(self, B, H, W):
         """(mode, lam, box, flips): the random decisions of one batch (host side, tiny)."""
-        u = lambda: float(torch.rand((), generator=self.gen))
-        mode = 2 if u() < 0.5 else 1                                        # RandomChoice([cut_mix, mix_up])
+        rng = self.rng
+        mode = 2 if rng.random() < 0.5 else 1                               # RandomChoice([cut_mix, mix_up])
         alpha = self.cutmix_alpha if mode == 2 else self.mixup_alpha
-        lam = float(torch._sample_dirichlet(torch.tensor([alpha, alpha]), generator=self.gen)[0])   # Beta(a, a)
+        lam = float(rng.beta(alpha, alpha))
         box = None
         if mode == 2:
-            rx, ry = int(u() * W), int(u() * H)
+            rx, ry = int(rng.integers(0, W)), int(rng.integers(0, H))
             r = 0.5 * (1.0 - lam) ** 0.5
             hw, hh = int(r * W), int(r * H)
             x1, y1, x2, y2 = max(rx - hw, 0), max(ry - hh, 0), min(rx + hw, W), min(ry + hh, H)
             box = (y1, y2, x1, x2)
             lam = 1.0 - (x2 - x1) * (y2 - y1) / float(W * H)
-        flips = (torch.rand(B, generator=self.gen) < self.flip_p).to(torch.uint8)
+        flips = torch.from_numpy((rng.random(B) < self.flip_p).astype("uint8"))
         return mode, lam, box, flips
 
     def __call__(self, img_u8, labels, decisions=None):
