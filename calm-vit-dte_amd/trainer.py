@@ -196,14 +196,16 @@ class TrainStep:
                 # calm_optim_step; the scale then backs off (x backoff) on inf/NaN or grows (x growth) after
                 # growth_interval clean steps, exactly as scaler.step() / scaler.update() would do it
                 sc = self.scaler
-                stats = self.opt.step(grad_scale=sc._scale)
                 if not hasattr(self, "_clean_steps"):
-                    self._clean_steps = torch.zeros((), dtype=torch.int32, device=stats.device)
+                    self._clean_steps = torch.zeros((), dtype=torch.int32, device=loss.device)
+                    self._one = torch.ones((), dtype=torch.float32, device=loss.device)
+                scale = sc.scale(self._one)                      # the current scale as a device tensor, no host sync
+                stats = self.opt.step(grad_scale=scale)
                 bad = stats[1] > 0
                 self._clean_steps = torch.where(bad, torch.zeros_like(self._clean_steps), self._clean_steps + 1)
                 grow = self._clean_steps >= sc.get_growth_interval()
-                new_scale = torch.where(bad, sc._scale * sc.get_backoff_factor(),
-                                        torch.where(grow, sc._scale * sc.get_growth_factor(), sc._scale))
+                new_scale = torch.where(bad, scale * sc.get_backoff_factor(),
+                                        torch.where(grow, scale * sc.get_growth_factor(), scale))
                 self._clean_steps = torch.where(grow, torch.zeros_like(self._clean_steps), self._clean_steps)
                 sc.update(new_scale.detach())
             else:
