@@ -1,0 +1,87 @@
+"""Bench-size checks (BASELINE configs[1]: M = 256*224 = 57344 token rows, D = 672): at these sizes the CPU oracle is
+too slow, so the kernels are checked through size-independent properties and against fp32 library math on the device."""
+import math
+
+import pytest
+import torch
+
+import calm_vit_dte_amd as calm
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def g(*shape, seed=0, scale=1.0):
+    gen = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randn(*shape, generator=gen, device="cuda") * scale
+
+
+def test_large_linear_forward_dgrad_wgrad_against_library_matmul_and_linearity():
+    be = calm.backend.get_backend()
+    M, N, K = 57344, 672, 672
+    x, x2, w, dy = g(M, K, seed=1), g(M, K, seed=2), g(N, K, seed=3, scale=K ** -0.5), g(M, N, seed=4)
+    sigma = torch.tensor([1.7], device="cuda")
+    lin = (K, 1, 0, 0)
+    y, y2, y12 = (torch.empty(M, N, device="cuda") for _ in range(3))
+    be.gemm(x, w, y, M, N, K, lin, lin, (N, 0, 0), inv_scale=sigma, split_k=1)
+    assert rel_err(y, (x @ w.T) / 1.7) < 1e-5
+    be.gemm(x2, w, y2, M, N, K, lin, lin, (N, 0, 0), inv_scale=sigma, split_k=1)
+    be.gemm(x + x2, w, y12, M, N, K, lin, lin, (N, 0, 0), inv_scale=sigma, split_k=1)
+    assert rel_err(y12, y + y2) < 1e-5                                   # linearity in the activations
+    dx = torch.empty(M, K, device="cuda")
+    be.gemm(dy, w, dx, M, K, N, (N, 1, 0, 0), (1, K, 0, 0), (K, 0, 0), inv_scale=sigma, split_k=1)
+    assert rel_err(dx, (dy @ w) / 1.7) < 1e-5
+    G = torch.empty(N, K, device="cuda")
+    be.gemm(dy, x, G, N, K, M, (1, N, 0, 0), (1, K, 0, 0), (K, 0, 0))    # split-K over 57344 tokens, fp32 atomics
+    assert rel_err(G, dy.T @ x) < 1e-5
+    # grouped q/k/v: same numbers as three separate launches
+    ws = [g(N, K, seed=10 + i, scale=K ** -0.5) for i in range(3)]
+    sg = [torch.tensor([1.0 + 0.3 * i], device="cuda") for i in range(3)]
+    outs = [torch.empty(M, N, device="cuda") for _ in range(3)]
+    be.gemm(x, ws, outs, M, N, K, lin, lin, (N, 0, 0), batch=(3, 1), inv_scale=sg, split_k=1)
+    for i in range(3):
+        be.gemm(x, ws[i], y, M, N, K, lin, lin, (N, 0, 0), inv_scale=sg[i], split_k=1)
+        assert torch.equal(outs[i], y)
+
+
+def test_attention_forward_at_bench_size_properties():
+    be = calm.backend.get_backend()
+    B, S, H, hd = 256, 224, 6, 112
+    D = H * hd
+    q, k, v = g(B, S, D, seed=1, scale=0.3), g(B, S, D, seed=2, scale=0.3), g(B, S, D, seed=3)
+    w1, b1 = g(2 * S, S, seed=4, scale=S ** -0.5), g(2 * S, seed=5, scale=0.1)
+    w2, b2 = g(S, 2 * S, seed=6, scale=(2 * S) ** -0.5), g(S, seed=7, scale=0.1)
+    s1, s2 = torch.tensor([0.9], device="cuda"), torch.tensor([1.2], device="cuda")
+    e = lambda *s: torch.empty(*s, device="cuda")
+    out, R, hp, hg, Mk, P = e(B, S, D), e(B, S, S), e(B, S, 2 * S), e(B, S, 2 * S), e(B, S, S), e(B, H, S, S)
+    be.attn_fwd(q, k, v, w1, b1, s1, w2, b2, s2, out, R, hp, hg, Mk, P, B, S, S, H, hd)
+    assert torch.allclose(P.sum(dim=-1), torch.ones(B, H, S, device="cuda"), atol=2e-5)      # softmax rows
+    assert rel_err(R[:4], torch.einsum("bid,bjd->bij", q[:4], k[:4])) < 1e-5                 # raw QK^T over all heads
+    # a slice of images against the library math (mask along the key axis, additive, shared by the heads)
+    n = 3
+    mask = (torch.nn.functional.gelu(R[:n] @ w1.T / 0.9 + b1) @ w2.T / 1.2 + b2)
+    assert rel_err(Mk[:n], mask) < 1e-4
+    qh, kh, vh = (t[:n].view(n, S, H, hd).transpose(1, 2) for t in (q, k, v))
+    ref = torch.softmax(qh @ kh.transpose(-1, -2) / math.sqrt(hd) + mask[:, None], dim=-1) @ vh
+    assert rel_err(out[:n], ref.transpose(1, 2).reshape(n, S, D)) < 1e-4
+    # images are independent: the first image alone gives the same bits
+    out1, P1 = e(1, S, D), e(1, H, S, S)
+    be.attn_fwd(q[:1], k[:1], v[:1], w1, b1, s1, w2, b2, s2, out1, e(1, S, S), e(1, S, 2 * S), e(1, S, 2 * S),
+                e(1, S, S), P1, 1, S, S, H, hd)
+    assert torch.equal(out1, out[:1]) and torch.equal(P1, P[:1])
+
+
+def test_tokenisation_round_trips_at_bench_size():
+    be = calm.backend.get_backend()
+    B, S = 256, 224
+    img = g(B, 3, S, S, seed=1)
+    rows, back, t1, t2 = (torch.empty(B, S, 3 * S, device="cuda") for _ in range(4))
+    be.image_to_rows(img, rows, B, S)
+    assert torch.equal(rows, img.permute(0, 2, 3, 1).reshape(B, S, 3 * S))
+    img2 = torch.empty_like(img)
+    be.rows_to_image(rows, img2, B, S)
+    assert torch.equal(img2, img)
+    be.grid_transpose(rows, t1, B, S)
+    be.grid_transpose(t1, t2, B, S)
+    assert torch.equal(t2, rows)                                           # involution, bit-exact
+    assert torch.equal(t1, rows.view(B, S, S, 3).transpose(1, 2).reshape(B, S, 3 * S))
