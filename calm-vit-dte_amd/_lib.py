@@ -71,6 +71,7 @@ SIGNATURES = {
     "calm_rope_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "calm_softmax_fwd": (_i32, [_p, _i64, _i32, _p]),
     "calm_softmax_bwd": (_i32, [_p, _p, _i64, _i32, _p]),
+    "calm_softmax_bwd_heads": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "calm_sum_heads": (_i32, [_p, _p, _i32, _i32, _i64, _p]),
     "calm_attention_fwd_supported": (_i32, [_i32, _i32, _i32, _i32]),
     "calm_attention_fwd": (_i32, [_p] * 15 + [_i32] * 5 + [_p]),

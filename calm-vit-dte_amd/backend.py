@@ -204,6 +204,10 @@ class HipBackend:
     def softmax_bwd(self, p, dp, rows, cols):
         _lib.check(self.lib.calm_softmax_bwd(_ptr(p), _ptr(dp), rows, cols, _stream()), "calm_softmax_bwd")
 
+    def softmax_bwd_heads(self, p, dp, dm, B, H, Sq, cols):
+        _lib.check(self.lib.calm_softmax_bwd_heads(_ptr(p), _ptr(dp), _ptr(dm), B, H, Sq, cols, _stream()),
+                   "calm_softmax_bwd_heads")
+
     def sum_heads(self, dl, dm, B, H, per_head):
         _lib.check(self.lib.calm_sum_heads(_ptr(dl), _ptr(dm), B, H, per_head, _stream()), "calm_sum_heads")
 

@@ -343,6 +343,49 @@ __global__ __launch_bounds__(NT) void softmax_bwd_kernel(const float* __restrict
     }
 }
 
+// softmax backward of all H heads of one (image, query) row by one wave, with the head-sum of the results — the
+// gradient of the head-broadcast mask (Vi_Tools:291) — kept in registers: saves sum_heads' re-read of dL.
+__global__ __launch_bounds__(NT) void softmax_bwd_heads_kernel(const float* __restrict__ p, float* __restrict__ dp,
+                                                               float* __restrict__ dm, long n_bq, int H, int Sq, int cols) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
+    const long nwaves = (long)gridDim.x * (NT / 64);
+    for (long bq = wave; bq < n_bq; bq += nwaves) {
+        const long b = bq / Sq, i = bq - b * Sq;
+        float msum[SM_MAXC];
+#pragma unroll
+        for (int u = 0; u < SM_MAXC; ++u) msum[u] = 0.f;
+        for (int hh = 0; hh < H; ++hh) {
+            const long row = (b * H + hh) * Sq + i;
+            const float* pr = p + row * cols;
+            float* gr = dp + row * cols;
+            float pv[SM_MAXC], gv[SM_MAXC];
+            float s = 0.f;
+#pragma unroll
+            for (int u = 0; u < SM_MAXC; ++u) {
+                const int c = lane + 64 * u;
+                pv[u] = c < cols ? pr[c] : 0.f;
+                gv[u] = c < cols ? gr[c] : 0.f;
+                s += pv[u] * gv[u];
+            }
+            s = wave_sum(s);
+#pragma unroll
+            for (int u = 0; u < SM_MAXC; ++u) {
+                const int c = lane + 64 * u;
+                const float d = pv[u] * (gv[u] - s);
+                if (c < cols) gr[c] = d;
+                msum[u] += d;
+            }
+        }
+        float* mr = dm + bq * cols;
+#pragma unroll
+        for (int u = 0; u < SM_MAXC; ++u) {
+            const int c = lane + 64 * u;
+            if (c < cols) mr[c] = msum[u];
+        }
+    }
+}
+
 __global__ __launch_bounds__(NT) void sum_heads_kernel(const float* __restrict__ dl, float* __restrict__ dm,
                                                        int B, int H, long per_head) {
     const long total = (long)B * per_head;
@@ -609,6 +652,17 @@ int calm_softmax_bwd(const float* p, float* dp, int64_t rows, int32_t cols, void
     if (cols > 64 * SM_MAXC) return CALM_E_UNSUPP;
     hipLaunchKernelGGL(softmax_bwd_kernel, dim3(grid_for(rows, NT / 64)), dim3(NT), 0, as_stream(stream), p, dp,
                        (long)rows, cols);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+int calm_softmax_bwd_heads(const float* p, float* dp, float* dm, int32_t B, int32_t H, int32_t Sq, int32_t cols,
+                           void* stream) {
+    if (!p || !dp || !dm || B <= 0 || H <= 0 || Sq <= 0 || cols <= 0) return CALM_E_INVAL;
+    if (cols > 64 * SM_MAXC) return CALM_E_UNSUPP;
+    const long n_bq = (long)B * Sq;
+    hipLaunchKernelGGL(softmax_bwd_heads_kernel, dim3(grid_for(n_bq, NT / 64)), dim3(NT), 0, as_stream(stream), p, dp, dm,
+                       n_bq, H, Sq, cols);
     CALM_LAUNCH_CHECK();
     return 0;
 }

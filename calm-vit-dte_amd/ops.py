@@ -469,8 +469,7 @@ class LatentMaskAttentionFn(Function):
             # dP = dO V^T ; dV = P^T dO
             be.gemm(dout, v, dP, Sq, Skv, hd, (D, 1, Sq * D, hd), (D, 1, Skv * D, hd), (Skv,) + pb, batch=(B, H))
             be.gemm(P, dout, dv, Skv, hd, Sq, (1, Skv) + pb, (1, D, Sq * D, hd), (D, Skv * D, hd), batch=(B, H))
-            be.softmax_bwd(P, dP, B * H * Sq, Skv)                 # dP now holds dL
-            be.sum_heads(dP, dM, B, H, Sq * Skv)
+            be.softmax_bwd_heads(P, dP, dM, B, H, Sq, Skv)         # dP now holds dL, dM its sum over the heads
             be.gemm(dP, k, dq, Sq, hd, Skv, (Skv, 1) + pb, (1, D, Skv * D, hd), (D, Sq * D, hd), batch=(B, H),
                     alpha=scale)
             be.gemm(dP, q, dk, Skv, hd, Sq, (1, Skv) + pb, (1, D, Sq * D, hd), (D, Skv * D, hd), batch=(B, H),

@@ -139,6 +139,9 @@ int calm_rope_bwd(const float* d_out, const float* xr, const float* table,
  * ------------------------------------------------------------------------------------- */
 int calm_softmax_fwd(float* x, int64_t rows, int32_t cols, void* stream);
 int calm_softmax_bwd(const float* p, float* dp, int64_t rows, int32_t cols, void* stream);
+/* the two steps above in one pass for P, dP: [B,H,Sq,cols]: dP <- softmax backward, dm[b,i,j] = sum_h dP[b,h,i,j] */
+int calm_softmax_bwd_heads(const float* p, float* dp, float* dm, int32_t B, int32_t H, int32_t Sq, int32_t cols,
+                           void* stream);
 int calm_sum_heads(const float* dl, float* dm, int32_t B, int32_t H, int64_t per_head, void* stream);
 
 /* ---------------------------------------------------------------------------------------

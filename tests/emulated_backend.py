@@ -220,6 +220,10 @@ class EmulatedBackend:
         s = (pv * gv).sum(dim=1, keepdim=True)
         gv.copy_(pv * (gv - s))
 
+    def softmax_bwd_heads(self, p, dp, dm, B, H, Sq, cols):
+        self.softmax_bwd(p, dp, B * H * Sq, cols)
+        self.sum_heads(dp, dm, B, H, Sq * cols)
+
     def sum_heads(self, dl, dm, B, H, per_head):
         dm.view(B, per_head).copy_(dl.view(B, H, per_head).sum(dim=1))
 

@@ -213,6 +213,19 @@ def test_sum_heads(hip, emu):
     assert rel_err(b, a) < TOL
 
 
+@pytest.mark.parametrize("B_,H,Sq,cols", [(2, 6, 48, 48), (3, 4, 20, 200), (1, 12, 37, 384), (2, 3, 5, 7)])
+def test_softmax_backward_with_head_sum(hip, emu, B_, H, Sq, cols):
+    """dL = softmax backward of [B,H,Sq,cols] and dM = sum over the heads in one pass, against the two-step form."""
+    P = torch.softmax(rnd(B_, H, Sq, cols, seed=1) * 2, dim=-1)
+    dP = rnd(B_, H, Sq, cols, seed=2)
+    g_ref, g_hip = dP.clone(), dP.clone().cuda()
+    m_ref, m_hip = torch.empty(B_, Sq, cols), torch.full((B_, Sq, cols), 3.0).cuda()
+    emu.softmax_bwd_heads(P, g_ref, m_ref, B_, H, Sq, cols)
+    hip.softmax_bwd_heads(P.cuda(), g_hip, m_hip, B_, H, Sq, cols)
+    assert rel_err(g_hip, g_ref) < TOL and rel_err(m_hip, m_ref) < TOL
+    assert rel_err(m_hip, g_hip.sum(dim=1)) < 1e-5
+
+
 @pytest.mark.parametrize("with_noise", [True, False])
 def test_latent(hip, emu, with_noise):
     rows, mvh = 2 * 16, 24
