@@ -69,40 +69,44 @@ __device__ __forceinline__ void group_rescale(const GemmP& p, f32x16 (&acc)[MT][
 // k-block (K % BK != 0) takes the masked form.
 template <bool KC, int ROWS>
 struct OperandCursor {
-    const float* ptr[NREG / 4];
+    const float* base;               // uniform (SGPR pair): tile origin at the current k-block
+    unsigned off[NREG / 4];          // per-thread byte offsets from it (constant over the k-loop)
     long step;
-    __device__ __forceinline__ void init(const float* base, long rs, long cs, int row0, int nrows_all, int k0) {
+    __device__ __forceinline__ void init(const float* origin, long rs, long cs, int row0, int nrows_all, int k0) {
         const int tid = threadIdx.x;
-        const int last = min(nrows_all, row0 + ROWS) - 1;
+        const int last = min(nrows_all - row0, ROWS) - 1;        // last live row of the tile, tile-local
         if constexpr (KC) {
             constexpr int KQ = BK / 4, RPP = NTHREADS / KQ;
+            base = origin + (long)row0 * rs + k0;
 #pragma unroll
             for (int i = 0; i < NREG / 4; ++i)
-                ptr[i] = base + (long)min(row0 + (tid / KQ) + RPP * i, last) * rs + k0 + 4 * (tid % KQ);
+                off[i] = (unsigned)(min((tid / KQ) + RPP * i, last) * rs + 4 * (tid % KQ)) * 4u;
             step = BK;
         } else {
-            const int row = min(row0 + 4 * (tid & 31), last & ~3);      // rows come in aligned groups of 4 (M % 4 == 0)
+            base = origin + (long)k0 * cs + row0;
+            const int row = min(4 * (tid & 31), last & ~3);      // rows come in aligned groups of 4 (M % 4 == 0)
 #pragma unroll
-            for (int i = 0; i < NREG / 4; ++i) ptr[i] = base + (long)(k0 + (tid >> 5) + 8 * i) * cs + row;
+            for (int i = 0; i < NREG / 4; ++i) off[i] = (unsigned)(((tid >> 5) + 8 * i) * cs + row) * 4u;
             step = BK * cs;
         }
     }
     // k_left = K - k0 (> 0); full k-blocks take the unconditional form
     __device__ __forceinline__ void load(int k_left, float (&reg)[NREG]) {
         const int tid = threadIdx.x;
+        const char* b = reinterpret_cast<const char*>(base);
 #pragma unroll
         for (int i = 0; i < NREG / 4; ++i) {
             f32x4 v;
             if (k_left >= BK) {
-                v = *reinterpret_cast<const f32x4*>(ptr[i]);
+                v = *reinterpret_cast<const f32x4*>(b + off[i]);
             } else {
                 const int k = KC ? 4 * (tid % (BK / 4)) : (tid >> 5) + 8 * i;
                 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (k < k_left) v = *reinterpret_cast<const f32x4*>(ptr[i]);
+                if (k < k_left) v = *reinterpret_cast<const f32x4*>(b + off[i]);
             }
-            ptr[i] += step;
             reg[4 * i + 0] = v[0]; reg[4 * i + 1] = v[1]; reg[4 * i + 2] = v[2]; reg[4 * i + 3] = v[3];
         }
+        base += step;
     }
 };
 
@@ -474,37 +478,41 @@ __device__ __forceinline__ void c_load(const float* __restrict__ base, long rs, 
 // unconditional 16-byte loads for full k-blocks
 template <bool KC, int ROWS>
 struct CCursor {
-    const float* ptr[4];
+    const float* base;
+    unsigned off[4];
     long step;
-    __device__ __forceinline__ void init(const float* base, long rs, long cs, int row0, int nrows_all, int k0) {
+    __device__ __forceinline__ void init(const float* origin, long rs, long cs, int row0, int nrows_all, int k0) {
         const int tid = threadIdx.x;
-        const int last = min(nrows_all, row0 + ROWS) - 1;
+        const int last = min(nrows_all - row0, ROWS) - 1;
         if constexpr (KC) {
+            base = origin + (long)row0 * rs + k0;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ptr[i] = base + (long)min(row0 + (tid >> 3) + 32 * i, last) * rs + k0 + 4 * (tid & 7);
+            for (int i = 0; i < 4; ++i) off[i] = (unsigned)(min((tid >> 3) + 32 * i, last) * rs + 4 * (tid & 7)) * 4u;
             step = CK;
         } else {
-            const int row = min(row0 + 4 * (tid & 31), last & ~3);
+            base = origin + (long)k0 * cs + row0;
+            const int row = min(4 * (tid & 31), last & ~3);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ptr[j] = base + (long)(k0 + 4 * (tid >> 5) + j) * cs + row;
+            for (int j = 0; j < 4; ++j) off[j] = (unsigned)((4 * (tid >> 5) + j) * cs + row) * 4u;
             step = CK * cs;
         }
     }
     __device__ __forceinline__ void load(int k_left, f32x4 (&reg)[4]) {
         const int tid = threadIdx.x;
+        const char* b = reinterpret_cast<const char*>(base);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f32x4 v;
             if (k_left >= CK) {
-                v = *reinterpret_cast<const f32x4*>(ptr[i]);
+                v = *reinterpret_cast<const f32x4*>(b + off[i]);
             } else {
                 const int k = KC ? 4 * (tid & 7) : 4 * (tid >> 5) + i;
                 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (k < k_left) v = *reinterpret_cast<const f32x4*>(ptr[i]);
+                if (k < k_left) v = *reinterpret_cast<const f32x4*>(b + off[i]);
             }
-            ptr[i] += step;
             reg[i] = v;
         }
+        base += step;
     }
 };
 
@@ -534,18 +542,18 @@ __device__ __forceinline__ void c_store(__bf16* __restrict__ hi_plane, __bf16* _
 }
 
 // MFMA A/B fragment (8 consecutive k for row `rowbase + (lane&31)`, k = 16*s + 8*(lane>>5) + 0..7)
-template <bool KC>
+template <bool KC, int LD = MC_LD>
 __device__ __forceinline__ bf16x8 c_frag(const __bf16* __restrict__ plane, int rowbase, int s, int lane) {
     if constexpr (KC) {
         return *reinterpret_cast<const bf16x8*>(plane + (rowbase + (lane & 31)) * KC_LD + 16 * s + 8 * (lane >> 5));
     } else {
         // hardware transpose read: each 16-lane group fetches a 4(k) x 16(row) block and gets it column-major
         const int q = (lane & 15) >> 2, pp = lane & 3, gi = lane >> 4;
-        const __bf16* a0 = plane + (16 * s + 8 * (gi >> 1) + q) * MC_LD + rowbase + 16 * (gi & 1) + 4 * pp;
+        const __bf16* a0 = plane + (16 * s + 8 * (gi >> 1) + q) * LD + rowbase + 16 * (gi & 1) + 4 * pp;
         const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
             (__attribute__((address_space(3))) s16x4*)(a0));
         const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-            (__attribute__((address_space(3))) s16x4*)(a0 + 4 * MC_LD));
+            (__attribute__((address_space(3))) s16x4*)(a0 + 4 * LD));
         s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
         return __builtin_bit_cast(bf16x8, v);
     }
@@ -655,6 +663,163 @@ __global__ __launch_bounds__(NTHREADS, NPASS == 3 ? 2 : CALM_GEMM_BF16_WAVES) vo
     gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
 }
 
+// ---- wide tile of the bf16-operand family: 256x128x32 per 512-thread workgroup (8 waves as 4x2, each 64x64) ----
+// The 128-row tiles above are bound by re-reading the fp32 operand panels from L2 / Infinity Cache (32 flop per
+// byte staged); 256 rows raise that to 42.7.  60 KB LDS, <=128 VGPRs: two workgroups (16 waves) per CU.  Used for
+// the data-parallel launches (forward, data gradients) with enough tiles to fill the chip; NPASS == 1 only.
+constexpr int WTHREADS = 512, WBM = 256, WBN = 128;
+#ifndef CALM_GEMM_WIDE_MIN_TILES
+#define CALM_GEMM_WIDE_MIN_TILES 512
+#endif
+constexpr int MC_LDW = 288;                  // bf16 per k-row of a 256-row [k][row] image (same bank residue as 160)
+constexpr int WPLANE_A = WBM * KC_LD;        // 20480 B (>= 32 * MC_LDW)
+
+template <bool KC, int ROWS>
+struct WCursor {
+    static constexpr int NV = ROWS * CK / (4 * WTHREADS);     // 16-byte vectors per thread per k-tile (4 or 2)
+    static constexpr int LD = ROWS == WBM ? MC_LDW : MC_LD;
+    const float* base;
+    unsigned off[NV];
+    long step;
+    __device__ __forceinline__ void init(const float* origin, long rs, long cs, int row0, int nrows_all, int k0) {
+        const int tid = threadIdx.x;
+        const int last = min(nrows_all - row0, ROWS) - 1;
+        if constexpr (KC) {
+            base = origin + (long)row0 * rs + k0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) off[i] = (unsigned)(min((tid >> 3) + 64 * i, last) * rs + 4 * (tid & 7)) * 4u;
+            step = CK;
+        } else {
+            constexpr int LPR = ROWS / 4;                     // threads across the rows
+            base = origin + (long)k0 * cs + row0;
+            const int row = min(4 * (tid % LPR), last & ~3);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) off[j] = (unsigned)((NV * (tid / LPR) + j) * cs + row) * 4u;
+            step = CK * cs;
+        }
+    }
+    __device__ __forceinline__ void load(int k_left, f32x4 (&reg)[NV]) {
+        const int tid = threadIdx.x;
+        const char* b = reinterpret_cast<const char*>(base);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            f32x4 v;
+            if (k_left >= CK) {
+                v = *reinterpret_cast<const f32x4*>(b + off[i]);
+            } else {
+                const int k = KC ? 4 * (tid & 7) : NV * (tid / (ROWS / 4)) + i;
+                v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (k < k_left) v = *reinterpret_cast<const f32x4*>(b + off[i]);
+            }
+            reg[i] = v;
+        }
+        base += step;
+    }
+    __device__ __forceinline__ void store(__bf16* __restrict__ plane, const f32x4 (&reg)[NV]) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            bf16x4 hi, lo;
+            split4<1>(reg[i], hi, lo);
+            int off;
+            if constexpr (KC) off = ((tid >> 3) + 64 * i) * KC_LD + 4 * (tid & 7);
+            else off = (NV * (tid / (ROWS / 4)) + i) * LD + 4 * (tid % (ROWS / 4));
+            *reinterpret_cast<bf16x4*>(plane + off) = hi;
+        }
+    }
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) {
+    constexpr int MT = 2, NT = 2;
+    __shared__ __attribute__((aligned(16))) __bf16 lds_a[2][WPLANE_A];
+    __shared__ __attribute__((aligned(16))) __bf16 lds_b[2][PLANE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int tiles = p.tiles_m * p.tiles_n;
+    int lin = blockIdx.x;
+    if (tiles >= 8) {
+        const int q = tiles >> 3, rem = tiles & 7, x = lin & 7, idx = lin >> 3;
+        lin = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + idx;
+    }
+    const int tn = lin % p.tiles_n, tm = lin / p.tiles_n;
+    const int m0 = tm * WBM, n0 = tn * WBN;
+    const int z = blockIdx.y;
+    const int kb_begin = z * p.kb_per_z;
+    const int kb_end = min(kb_begin + p.kb_per_z, p.kb_total);
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    WCursor<AKC, WBM> ca;
+    WCursor<BKC, WBN> cb;
+    f32x4 ra[WCursor<AKC, WBM>::NV], rb[WCursor<BKC, WBN>::NV];
+    int cur_b = -1;
+    auto fetch = [&](int kb) {
+        const int b = p.kb_total == p.kpb ? 0 : kb / p.kpb;
+        const int k0 = (kb - b * p.kpb) * CK;
+        if (b != cur_b) {
+            const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
+            ca.init(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, k0);
+            cb.init(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
+            cur_b = b;
+        }
+        ca.load(p.K - k0, ra);
+        cb.load(p.K - k0, rb);
+    };
+
+    int buf = 0;
+    if (kb_begin < kb_end) {
+        fetch(kb_begin);
+        ca.store(lds_a[0], ra);
+        cb.store(lds_b[0], rb);
+    }
+    __syncthreads();
+
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+        const bool more = kb + 1 < kb_end;
+        if (p.reduce_group && kb != kb_begin && kb % p.kpb == 0) group_rescale<MT, NT>(p, acc, kb / p.kpb);
+        if (more) fetch(kb + 1);
+#pragma unroll
+        for (int s = 0; s < CK / 16; ++s) {
+            bf16x8 af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = c_frag<AKC, MC_LDW>(lds_a[buf], wm * 64 + 32 * i, s, lane);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = c_frag<BKC, MC_LD>(lds_b[buf], wn * 64 + 32 * j, s, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            ca.store(lds_a[buf ^ 1], ra);
+            cb.store(lds_b[buf ^ 1], rb);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
+}
+
+int launch_wide(const GemmP& p, dim3 grid, bool akc, bool bkc, hipStream_t s) {
+    if (akc && bkc) hipLaunchKernelGGL((gemm_bf16w_kernel<true, true>), grid, dim3(WTHREADS), 0, s, p);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16w_kernel<true, false>), grid, dim3(WTHREADS), 0, s, p);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf16w_kernel<false, true>), grid, dim3(WTHREADS), 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16w_kernel<false, false>), grid, dim3(WTHREADS), 0, s, p);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
 template <bool AKC, bool BKC, int NPASS>
 int launch_c(const GemmP& p, dim3 grid, int bn, hipStream_t s) {
     if (bn == 128) hipLaunchKernelGGL((gemm_bf16c_kernel<AKC, BKC, NPASS, 128>), grid, dim3(NTHREADS), 0, s, p);
@@ -689,6 +854,8 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     if (a->dtype != CALM_F32 && a->dtype != CALM_BF16 && a->dtype != CALM_BF16X3) return CALM_E_UNSUPP;
     if (a->a_rs != 1 && a->a_cs != 1) return CALM_E_LAYOUT;
     if (a->b_rs != 1 && a->b_cs != 1) return CALM_E_LAYOUT;
+    // the staging cursors address a tile with 32-bit byte offsets from a per-tile base
+    if (a->a_rs >= (1 << 22) || a->a_cs >= (1 << 22) || a->b_rs >= (1 << 22) || a->b_cs >= (1 << 22)) return CALM_E_UNSUPP;
     if (a->act == CALM_ACT_GELU_BWD && !a->aux) return CALM_E_INVAL;
     if (a->act < 0 || a->act > CALM_ACT_GELU_BWD) return CALM_E_INVAL;
     if (a->n_group < 0 || a->n_group > CALM_GEMM_MAX_GROUP) return CALM_E_INVAL;
@@ -758,6 +925,18 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
         const long cost96 = (items96 + cus - 1) / cus * 96, cost128 = (items128 + cus - 1) / cus * 128;
         bn = cost96 < cost128 ? 96 : 128;
     }
+    // bf16 operands, data-parallel launch with at least a full resident round (2 per CU) of 256x128 tiles: wide kernel
+    bool wide = false;
+    if (family == CALM_BF16 && !k_split) {
+        const long nb = grouped_reduce_unsplit ? 1 : batch;
+        const long rows_w = (long)(a->M + WBM - 1) / WBM * WBM;             // at most 1/8 of the rows padded
+        wide = 8 * rows_w <= 9 * (long)a->M &&
+               rows_w / WBM * ((a->N + WBN - 1) / WBN) * nb >= CALM_GEMM_WIDE_MIN_TILES;
+        if (wide) {
+            bn = WBN;
+            p.tiles_m = (a->M + WBM - 1) / WBM;
+        }
+    }
     p.tiles_n = (a->N + bn - 1) / bn;
     const int tiles = p.tiles_m * p.tiles_n;
 
@@ -825,6 +1004,7 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     if (gy > 65535) return CALM_E_UNSUPP;
     dim3 grid(tiles, gy);
 
+    if (wide) return launch_wide(p, grid, akc, bkc, s);
     if (family == CALM_BF16) return launch_c_layout<1>(p, grid, bn, akc, bkc, s);
     if (family == CALM_BF16X3) return launch_c_layout<3>(p, grid, bn, akc, bkc, s);
     if (vec) {

@@ -71,6 +71,38 @@ def test_bf16_operand_gemm(M, N, K, batch, akc, bkc, prec, tol, epi):
         assert rel_err(C_hip, C_exact) < 5e-5
 
 
+WIDE_CASES = [
+    # shapes with >= 512 tiles of 256x128: the wide bf16 kernel (ragged M, N and K tails in every layout)
+    (16388, 1000, 200, (1, 1), True, True),
+    (16388, 1000, 72, (1, 1), True, False),
+    (8200, 2060, 40, (1, 1), False, True),
+    (8200, 1924, 96, (1, 1), False, False),
+    (4100, 1000, 64, (2, 2), True, False),    # batched
+    (300, 200, 48, (32, 8), True, True),      # many small entries: 2 x 2 tiles each
+]
+
+
+@pytest.mark.parametrize("M,N,K,batch,akc,bkc", WIDE_CASES)
+@pytest.mark.parametrize("epi", ["plain", "full"])
+def test_bf16_wide_tile_gemm(M, N, K, batch, akc, bkc, epi):
+    hip, emu = calm.backend.get_backend(), EmulatedBackend()
+    b0, b1 = batch
+    A, a = _operand(M, K, batch, akc, 1)
+    B, b = _operand(N, K, batch, bkc, 2)
+    c = (N, b1 * M * N, M * N)
+    kw = {}
+    if epi == "full":
+        kw = dict(alpha=0.5, inv_scale=torch.tensor([1.3]), bias=rnd(N, seed=3), col_scale=rnd(N, seed=4),
+                  residual=rnd(b0, b1, M, N, seed=5), r=c, act=1)
+    kw_hip = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
+    C_ref, C_hip = torch.zeros(b0, b1, M, N), torch.full((b0, b1, M, N), 7.0).cuda()
+    calm.backend.set_matmul_precision("bf16")
+    emu.gemm(A, B, C_ref, M, N, K, a, b, c, batch=batch, split_k=1, **kw)
+    hip.gemm(A.cuda(), B.cuda(), C_hip, M, N, K, a, b, c, batch=batch, split_k=1, **kw_hip)
+    assert rel_err(C_hip, C_ref) < 2e-4
+    assert (C_hip.cpu() - C_ref).abs().max() < 2e-3 * C_ref.abs().max()     # no stray tile
+
+
 @pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
 def test_split_k_weight_gradient_in_bf16_modes(prec):
     hip, emu = calm.backend.get_backend(), EmulatedBackend()
