@@ -11,6 +11,7 @@
 // Workgroup ids are remapped so that consecutive tiles (n fastest: they share an A panel) land on
 // the same XCD / L2.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -90,14 +91,17 @@ struct OperandCursor {
             step = BK * cs;
         }
     }
-    // k_left = K - k0 (> 0); full k-blocks take the unconditional form
+    // k_left = K - k0 (> 0).  FULL: K is a whole number of k-blocks — the loads are unconditional (the kernel holds
+    // one copy of its k-loop per case: with a run-time choice in one loop the compiler folds both forms into the
+    // masked one, 16 zero fills and 4 exec-mask branches per iteration)
+    template <bool FULL>
     __device__ __forceinline__ void load(int k_left, float (&reg)[NREG]) {
         const int tid = threadIdx.x;
         const char* b = reinterpret_cast<const char*>(base);
 #pragma unroll
         for (int i = 0; i < NREG / 4; ++i) {
             f32x4 v;
-            if (k_left >= BK) {
+            if constexpr (FULL) {
                 v = *reinterpret_cast<const f32x4*>(b + off[i]);
             } else {
                 const int k = KC ? 4 * (tid % (BK / 4)) : (tid >> 5) + 8 * i;
@@ -357,27 +361,6 @@ __global__ __launch_bounds__(NTHREADS, BN_ == 96 ? CALM_GEMM_WAVES96 : CALM_GEMM
 
     OperandCursor<AKC, BM> ca;
     OperandCursor<BKC, BN_> cb;
-    int cur_b = -1;                       // batch entry the cursors point into
-    auto fetch = [&](int kb) {
-        const int b = p.kb_total == p.kpb ? 0 : kb / p.kpb;          // single-entry launches skip the divisions
-        const int k0 = (kb - b * p.kpb) * BK;
-        if constexpr (VEC == 4) {
-            if (b != cur_b) {                                         // wave-uniform: first fetch, or a batch boundary
-                const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
-                ca.init(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, k0);
-                cb.init(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
-                cur_b = b;
-            }
-            ca.load(p.K - k0, ra);
-            cb.load(p.K - k0, rb);
-        } else {
-            const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
-            load_operand<AKC, VEC, BM>(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0,
-                                       p.M, k0, p.K, ra);
-            load_operand<BKC, VEC, BN_>(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs,
-                                        n0, p.N, k0, p.K, rb);
-        }
-    };
     // the 8 k-pairs of one staged k-block: 1 (2) A and 3 (2) B fragments per 3 (4) MFMAs.  A wave whose rows all lie
     // past M (edge tile of a short M: the 40- and 176-row sequence-axis products) stages and synchronises but
     // issues no MFMAs: its accumulators are never stored.
@@ -404,21 +387,50 @@ __global__ __launch_bounds__(NTHREADS, BN_ == 96 ? CALM_GEMM_WAVES96 : CALM_GEMM
         store_operand<BKC, VEC, LDB, BN_>(Bs[buf], rb);
     };
 
-    int buf = 0;
-    if (kb_begin < kb_end) {
-        fetch(kb_begin);
-        stash(0);
-    }
-    __syncthreads();
-
-    for (int kb = kb_begin; kb < kb_end; ++kb) {
-        const bool more = kb + 1 < kb_end;
-        if (p.reduce_group && kb != kb_begin && kb % p.kpb == 0) group_rescale<MT, NT>(p, acc, kb / p.kpb);
-        if (more) fetch(kb + 1);
-        multiply(buf);
-        if (more) stash(buf ^ 1);
+    auto k_loop = [&](auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;
+        int cur_b = -1;                       // batch entry the cursors point into
+        auto fetch = [&](int kb) {
+            const int b = p.kb_total == p.kpb ? 0 : kb / p.kpb;          // single-entry launches skip the divisions
+            const int k0 = (kb - b * p.kpb) * BK;
+            if constexpr (VEC == 4) {
+                if (b != cur_b) {                                         // wave-uniform: first fetch, or a batch boundary
+                    const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
+                    ca.init(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, k0);
+                    cb.init(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
+                    cur_b = b;
+                }
+                ca.template load<FULL>(p.K - k0, ra);
+                cb.template load<FULL>(p.K - k0, rb);
+            } else {
+                const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
+                load_operand<AKC, VEC, BM>(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs,
+                                           m0, p.M, k0, p.K, ra);
+                load_operand<BKC, VEC, BN_>(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs,
+                                            p.b_cs, n0, p.N, k0, p.K, rb);
+            }
+        };
+        int buf = 0;
+        if (kb_begin < kb_end) {
+            fetch(kb_begin);
+            stash(0);
+        }
         __syncthreads();
-        buf ^= 1;
+        for (int kb = kb_begin; kb < kb_end; ++kb) {
+            const bool more = kb + 1 < kb_end;
+            if (p.reduce_group && kb != kb_begin && kb % p.kpb == 0) group_rescale<MT, NT>(p, acc, kb / p.kpb);
+            if (more) fetch(kb + 1);
+            multiply(buf);
+            if (more) stash(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
+    };
+    if constexpr (VEC == 4) {
+        if (p.K % BK == 0) k_loop(std::true_type{});
+        else k_loop(std::false_type{});
+    } else {
+        k_loop(std::false_type{});
     }
     // (a peeled loop without the per-iteration decisions for single-entry, whole-k-block launches measured +2% on
     // forward / input-gradient shapes, -2% on weight gradients and -0.6% on the training step: not kept)
