@@ -168,10 +168,13 @@ __device__ __forceinline__ void store_operand(float (*T)[LD], const float (&reg)
         if constexpr (KC) {
             constexpr int KQ = BK / 4, RPP = NTHREADS / KQ;
             const int kq = 4 * (tid % KQ);
+            // a wave stages 64 / KQ consecutive rows per pass: whether they lie past ROWS is wave-uniform (scalar branch)
+            const int wave_row = __builtin_amdgcn_readfirstlane(tid >> 6) * (64 / KQ);
 #pragma unroll
             for (int i = 0; i < NREG / 4; ++i) {
                 const int row = (tid / KQ) + RPP * i;
-                if (ROWS < 128 && row >= ROWS) continue;
+                if (ROWS < 128 && ROWS % (64 / KQ) == 0 && wave_row + RPP * i >= ROWS) continue;
+                if (ROWS < 128 && ROWS % (64 / KQ) != 0 && row >= ROWS) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) T[kq + j][row] = reg[4 * i + j];
             }
@@ -323,7 +326,7 @@ __global__ __launch_bounds__(NTHREADS, BN_ == 96 ? CALM_GEMM_WAVES96 : CALM_GEMM
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDB];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave id in an SGPR
     const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     const int r = lane & 31, h = lane >> 5;
 
@@ -410,20 +413,24 @@ __global__ __launch_bounds__(NTHREADS, BN_ == 96 ? CALM_GEMM_WAVES96 : CALM_GEMM
                                             p.b_cs, n0, p.N, k0, p.K, rb);
             }
         };
-        int buf = 0;
         if (kb_begin < kb_end) {
             fetch(kb_begin);
             stash(0);
         }
         __syncthreads();
-        for (int kb = kb_begin; kb < kb_end; ++kb) {
+        // two k-blocks per trip: the LDS stage of each half is a compile-time constant (no per-iteration address math)
+        auto step = [&](int kb, auto stage_tag) {
+            constexpr int ST = decltype(stage_tag)::value;
             const bool more = kb + 1 < kb_end;
             if (p.reduce_group && kb != kb_begin && kb % p.kpb == 0) group_rescale<MT, NT>(p, acc, kb / p.kpb);
             if (more) fetch(kb + 1);
-            multiply(buf);
-            if (more) stash(buf ^ 1);
+            multiply(ST);
+            if (more) stash(ST ^ 1);
             __syncthreads();
-            buf ^= 1;
+        };
+        for (int kb = kb_begin; kb < kb_end; kb += 2) {
+            step(kb, std::integral_constant<int, 0>{});
+            if (kb + 1 < kb_end) step(kb + 1, std::integral_constant<int, 1>{});
         }
     };
     if constexpr (VEC == 4) {
