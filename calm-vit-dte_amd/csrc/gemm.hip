@@ -516,13 +516,14 @@ struct CCursor {
             step = CK * cs;
         }
     }
+    template <bool FULL>
     __device__ __forceinline__ void load(int k_left, f32x4 (&reg)[4]) {
         const int tid = threadIdx.x;
         const char* b = reinterpret_cast<const char*>(base);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             f32x4 v;
-            if (k_left >= CK) {
+            if constexpr (FULL) {
                 v = *reinterpret_cast<const f32x4*>(b + off[i]);
             } else {
                 const int k = KC ? 4 * (tid & 7) : 4 * (tid >> 5) + i;
@@ -622,6 +623,9 @@ __global__ __launch_bounds__(NTHREADS, NPASS == 3 ? 2 : CALM_GEMM_BF16_WAVES) vo
     f32x4 ra[4], rb[4];
     CCursor<AKC, BM> ca;
     CCursor<BKC, BN_> cb;
+    // one copy of the k-loop per case (whole k-tiles / tailed K): see OperandCursor::load
+    auto k_loop = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
     int cur_b = -1;
     auto fetch = [&](int kb) {
         const int b = p.kb_total == p.kpb ? 0 : kb / p.kpb;
@@ -632,8 +636,8 @@ __global__ __launch_bounds__(NTHREADS, NPASS == 3 ? 2 : CALM_GEMM_BF16_WAVES) vo
             cb.init(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
             cur_b = b;
         }
-        ca.load(p.K - k0, ra);
-        cb.load(p.K - k0, rb);
+        ca.template load<FULL>(p.K - k0, ra);
+        cb.template load<FULL>(p.K - k0, rb);
     };
     auto stash = [&](int st) {
         c_store<AKC, NPASS>(lds[st][0][0], lds[st][0][NPL - 1], ra);
@@ -679,6 +683,9 @@ __global__ __launch_bounds__(NTHREADS, NPASS == 3 ? 2 : CALM_GEMM_BF16_WAVES) vo
         __syncthreads();
         buf ^= 1;
     }
+    };
+    if (p.K % CK == 0) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
     gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
 }
 
@@ -717,13 +724,14 @@ struct WCursor {
             step = CK * cs;
         }
     }
+    template <bool FULL>
     __device__ __forceinline__ void load(int k_left, f32x4 (&reg)[NV]) {
         const int tid = threadIdx.x;
         const char* b = reinterpret_cast<const char*>(base);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             f32x4 v;
-            if (k_left >= CK) {
+            if constexpr (FULL) {
                 v = *reinterpret_cast<const f32x4*>(b + off[i]);
             } else {
                 const int k = KC ? 4 * (tid & 7) : NV * (tid / (ROWS / 4)) + i;
@@ -781,6 +789,8 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
     WCursor<AKC, WBM> ca;
     WCursor<BKC, WBN> cb;
     f32x4 ra[WCursor<AKC, WBM>::NV], rb[WCursor<BKC, WBN>::NV];
+    auto k_loop = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
     int cur_b = -1;
     auto fetch = [&](int kb) {
         const int b = p.kb_total == p.kpb ? 0 : kb / p.kpb;
@@ -791,8 +801,8 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
             cb.init(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
             cur_b = b;
         }
-        ca.load(p.K - k0, ra);
-        cb.load(p.K - k0, rb);
+        ca.template load<FULL>(p.K - k0, ra);
+        cb.template load<FULL>(p.K - k0, rb);
     };
 
     int buf = 0;
@@ -827,6 +837,9 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
         __syncthreads();
         buf ^= 1;
     }
+    };
+    if (p.K % CK == 0) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
     gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
 }
 
