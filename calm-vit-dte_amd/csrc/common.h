@@ -21,7 +21,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ void gelu_parts_f(float x, float& cdf, float& gauss) {
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float e = __expf(-z * z);                       // e^{-x^2/2}
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+    // v_rcp_f32 (1 ulp) — __frcp_rn expands to the 10-instruction IEEE division sequence; the argument is >= 1 and
+    // the A-S polynomial's own error (1.5e-7) is above what one ulp of t contributes
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
     const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f),
                                         -0.284496736f), 0.254829592f);
     const float erf_abs = fmaf(-poly, e, 1.0f);           // erf(|x|/sqrt2)
