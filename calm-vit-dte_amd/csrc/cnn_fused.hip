@@ -74,11 +74,14 @@ __global__ __launch_bounds__(FW_NT) void cnn_fwd_kernel(const float* __restrict_
             xs[e] = (yy >= 0 && yy < S && xx >= 0 && xx < S) ? xb[((long)yy * S + xx) * 3 + ch] : 0.f;
         }
         __syncthreads();
+        // (out-of-image pixels: computed unconditionally on the zero-padded x and multiplied by 0 — a select makes the
+        // compiler wrap the GELU in an exec-mask branch, which keeps two unrolled iterations from interleaving)
+#pragma unroll 2
         for (int p = g; p < FH * FH; p += FG) {
             const int yy = y0 - 1 + p / FH, xx = x0 - 1 + p % FH;
-            const bool in = yy >= 0 && yy < S && xx >= 0 && xx < S;
+            const float in = (yy >= 0 && yy < S && xx >= 0 && xx < S) ? 1.f : 0.f;
             const f32x2 z = w0r[0] * xs[3 * p] + w0r[1] * xs[3 * p + 1] + w0r[2] * xs[3 * p + 2] + b0r;
-            st2(&hs[p * PS + c], in ? gelu2(z) : (f32x2){0.f, 0.f});   // zero padding applies to the dwconv INPUT
+            st2(&hs[p * PS + c], gelu2(z) * in);                       // zero padding applies to the dwconv INPUT
         }
         __syncthreads();
         f32x2 h2[T * T / FG];
@@ -178,9 +181,9 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
 #pragma unroll 2
         for (int p = g; p < H2 * H2; p += BG) {
             const int yy = y0 - 2 + p / H2, xx = x0 - 2 + p % H2;
-            const bool in = yy >= 0 && yy < S && xx >= 0 && xx < S;
+            const float in = (yy >= 0 && yy < S && xx >= 0 && xx < S) ? 1.f : 0.f;
             const f32x2 z = w0r[0] * xs[3 * p] + w0r[1] * xs[3 * p + 1] + w0r[2] * xs[3 * p + 2] + b0r;
-            st2(&h1s[p * PS + c], in ? gelu2(z) : zero2);
+            st2(&h1s[p * PS + c], gelu2(z) * in);
         }
         __syncthreads();
         // dL/dh2p on the 18x18 region (+ weight grads of conv4 / dwconv on the tile's own pixels)
@@ -202,15 +205,15 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
             const f32x2 dh2 = w4r[0] * d0 + w4r[1] * d1 + w4r[2] * d2;
             f32x2 h2, dgelu;
             gelu2_both(z, h2, dgelu);
-            const f32x2 dz = in ? dh2 * dgelu : zero2;
+            const f32x2 dz = dh2 * dgelu;                  // dy is zero outside the image, hence so is dh2
             st2(&d2s[r * PS + c], dz);
-            const bool own = in && ry >= 1 && ry <= T && rx >= 1 && rx <= T;
-            if (own) {
-                a_g4[0] += h2 * d0; a_g4[1] += h2 * d1; a_g4[2] += h2 * d2;
-                a_gb2 += dz;
+            // weight gradients only from the tile's own pixels: a 0/1 factor instead of a branch
+            const float own = (in && ry >= 1 && ry <= T && rx >= 1 && rx <= T) ? 1.f : 0.f;
+            const f32x2 h2o = h2 * own, dzo = dz * own;
+            a_g4[0] += h2o * d0; a_g4[1] += h2o * d1; a_g4[2] += h2o * d2;
+            a_gb2 += dzo;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) a_g2[k] += dz * h1v[k];
-            }
+            for (int k = 0; k < 9; ++k) a_g2[k] += dzo * h1v[k];
         }
         __syncthreads();                                   // d2s complete, h1s no longer read
         // dL/dh1p on the tile; staged over the h1 image for the channel reduction of conv0^T
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
         for (int q = g; q < T * T; q += BG) {
             const int qy = q / T, qx = q % T;
             const int yy = y0 + qy, xx = x0 + qx;
-            const bool in = yy < S && xx < S;
+            const float in = (yy < S && xx < S) ? 1.f : 0.f;
             f32x2 dh1 = zero2;
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky)
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
             const int px = ((qy + 2) * H2 + qx + 2) * 3;
             const float x0v = xs[px], x1v = xs[px + 1], x2v = xs[px + 2];
             const f32x2 z = w0r[0] * x0v + w0r[1] * x1v + w0r[2] * x2v + b0r;
-            const f32x2 dz = in ? dh1 * gelu2_grad(z) : zero2;
+            const f32x2 dz = dh1 * gelu2_grad(z) * in;
             st2(&h1s[q * PS + c], dz);
             a_gb0 += dz;
             a_g0[0] += dz * x0v; a_g0[1] += dz * x1v; a_g0[2] += dz * x2v;
