@@ -569,12 +569,26 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kv_kernel(const AttnBwdP p) 
     const float* qb = p.q + (long)b * p.Sq * D;
     const float* dob = p.dout + (long)b * p.Sq * D;
 
-    auto stage = [&](const float* src) {                        // [Sq x hd] stripe (row stride D) -> bufV
-        for (int f = tid; f < v_total; f += NTH) {
-            const int row = f / v_per_row, cq = f - row * v_per_row;
-            f32x4v val = {0.f, 0.f, 0.f, 0.f};
-            if (4 * cq < hd) val = *reinterpret_cast<const f32x4v*>(src + (long)row * D + 4 * cq);
-            *reinterpret_cast<f32x4v*>(bufV + row * LDV + 4 * cq) = val;
+    // [Sq x hd] stripe (row stride D) -> bufV, four 16-byte loads in flight per thread and trip: as a rolled
+    // load -> store loop every trip waited out a full memory round trip (6-8 per stripe, two stripes per head)
+    constexpr int SB = 4;
+    auto stage = [&](const float* src) {
+#pragma unroll 1
+        for (int f0 = tid; f0 < v_total; f0 += SB * NTH) {
+            f32x4v val[SB];
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int f = f0 + u * NTH;
+                const int row = f / v_per_row, cq = f - row * v_per_row;
+                val[u] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+                if (f < v_total && 4 * cq < hd) val[u] = *reinterpret_cast<const f32x4v*>(src + (long)row * D + 4 * cq);
+            }
+#pragma unroll
+            for (int u = 0; u < SB; ++u) {
+                const int f = f0 + u * NTH;
+                const int row = f / v_per_row, cq = f - row * v_per_row;
+                if (f < v_total) *reinterpret_cast<f32x4v*>(bufV + row * LDV + 4 * cq) = val[u];
+            }
         }
     };
     auto contract = [&](const f32x4v (&X)[NI], float* out_row, float scale) {   // out^T[d,j] = sum_i stripe[i,d] X[i,j]
