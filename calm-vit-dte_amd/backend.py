@@ -84,6 +84,8 @@ class OptimPlan:
             e["numel"] = p.numel()
             if r["sn"] is not None:
                 u, v, sigma, rows, cols = r["sn"]
+                if rows * cols != p.numel() or p.numel() >= 2 ** 31:      # the kernels index (row, col) in 32 bits
+                    raise ValueError("spectral-norm layer too large for the optimizer-side step")
                 e["sn_u"], e["sn_v"], e["sn_sigma"], e["rows"], e["cols"] = _ptr(u), _ptr(v), _ptr(sigma), rows, cols
             e["chunk0"] = len(chunk_tensor)
             chunk_tensor += [i] * ((p.numel() + chunk - 1) // chunk)

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(NT) void optim_stats(const calm_optim_tensor* __res
     if (e.sn_sigma) {
         for (long i = i0 + threadIdx.x; i < i1; i += NT) {
             const float g = e.grad[i];
-            const int r = (int)(i / e.cols), c = (int)(i - (long)r * e.cols);
+            // rows * cols < 2^31 for a spectral-norm layer (checked by the host): 32-bit division, not the 64-bit sequence
+            const unsigned r = (unsigned)i / (unsigned)e.cols, c = (unsigned)i - r * (unsigned)e.cols;
             s2 += g * g; gw += g * e.param[i]; guv += g * e.sn_u[r] * e.sn_v[c];
             bad |= !finite_f(g);
         }
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(NT) void optim_update(const calm_optim_tensor* __re
     for (long i = i0 + threadIdx.x; i < i1; i += NT) {
         float g = e.grad[i];
         if (sn) {
-            const int r = (int)(i / e.cols), cc = (int)(i - (long)r * e.cols);
+            const unsigned r = (unsigned)i / (unsigned)e.cols, cc = (unsigned)i - r * (unsigned)e.cols;
             g = (g - c * e.sn_u[r] * e.sn_v[cc]) * inv_sg;
         }
         g *= mul;

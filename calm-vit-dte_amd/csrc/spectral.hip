@@ -13,7 +13,7 @@
 namespace {
 
 constexpr int NT = 256;
-constexpr int ROWS_PER_WORK = 64;
+constexpr int ROWS_PER_WORK = 16;     // rows per work item (A/B: 64 -> 16, four times the blocks in flight over the 160 MB of weights)
 
 struct SnLayerDev {
     const float* w; float* u; float* v; float* sigma;
