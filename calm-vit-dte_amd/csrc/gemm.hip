@@ -774,9 +774,16 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
     }
     const int tn = lin % p.tiles_n, tm = lin / p.tiles_n;
     const int m0 = tm * WBM, n0 = tn * WBN;
-    const int z = blockIdx.y;
-    const int kb_begin = z * p.kb_per_z;
-    const int kb_end = min(kb_begin + p.kb_per_z, p.kb_total);
+    int z = blockIdx.y;
+    int kb_begin = z * p.kb_per_z;
+    int kb_end = min(kb_begin + p.kb_per_z, p.kb_total);
+    if (p.slices_per_batch) {                        // batched split-K (grouped weight gradients), as in the 128-row kernels
+        const int b = z / p.slices_per_batch, sl = z - b * p.slices_per_batch;
+        kb_begin = b * p.kpb + sl * p.kb_per_z;
+        kb_end = min(kb_begin + p.kb_per_z, (b + 1) * p.kpb);
+        z = b;
+    }
+    if (kb_begin >= kb_end && p.atomic) return;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -969,12 +976,21 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
             p.tiles_m = (a->M + WBM - 1) / WBM;
         }
     }
+    // ... and the split-K weight gradients (plain or grouped) whose output pads by at most 1/4 in 256-row tiles (672,
+    // 768, 1056, 1344 rows): with bf16 operands they are bound by re-reading the fp32 panels from L2, not by padded MFMAs
+    const bool wide_split = family == CALM_BF16 && k_split && !a->reduce_batch && (group_split || batch == 1) &&
+                            4 * ((long)(a->M + WBM - 1) / WBM * WBM) <= 5 * (long)a->M;
+    if (wide_split) {
+        wide = true;
+        bn = WBN;
+        p.tiles_m = (a->M + WBM - 1) / WBM;
+    }
     p.tiles_n = (a->N + bn - 1) / bn;
     const int tiles = p.tiles_m * p.tiles_n;
 
     // k-slices of a split launch: one resident round of workgroups (256 CUs x 5 for the 96-wide tile, x 4 for the
     // 128-wide one; A/B over the weight-gradient shapes: -3% time against 768, -12% on 1344x672)
-    const int split_slots = bn == 96 ? 256 * CALM_GEMM_WAVES96 : 256 * CALM_GEMM_WAVES;
+    const int split_slots = wide ? 256 * 2 : bn == 96 ? 256 * CALM_GEMM_WAVES96 : 256 * CALM_GEMM_WAVES;
     int nsplit = 1;
     p.atomic = 0;
     p.slices_per_batch = 0;

@@ -103,6 +103,35 @@ def test_bf16_wide_tile_gemm(M, N, K, batch, akc, bkc, epi):
     assert (C_hip.cpu() - C_ref).abs().max() < 2e-3 * C_ref.abs().max()     # no stray tile
 
 
+@pytest.mark.parametrize("M,N,K", [(672, 528, 8192), (1344, 100, 6000), (768, 672, 4104), (1056, 96, 12288)])
+def test_bf16_split_k_weight_gradient_on_the_wide_tile(M, N, K):
+    """Output rows that pad by <= 1/4 in 256-row tiles: the split-K weight gradient runs on the 256x128 kernel."""
+    hip, emu = calm.backend.get_backend(), EmulatedBackend()
+    dy, x = rnd(K, M, seed=1), rnd(K, N, seed=2)
+    G_ref, G_hip = torch.zeros(M, N), torch.full((M, N), 3.0).cuda()
+    args = (M, N, K, (1, M, 0, 0), (1, N, 0, 0), (N, 0, 0))
+    calm.backend.set_matmul_precision("bf16")
+    emu.gemm(dy, x, G_ref, *args)
+    hip.gemm(dy.cuda(), x.cuda(), G_hip, *args)
+    assert rel_err(G_hip, G_ref) < 2e-4
+
+
+@pytest.mark.parametrize("n,T,Dout,Din", [(3, 8192, 672, 96), (2, 4100, 768, 240)])
+def test_bf16_grouped_weight_gradients_on_the_wide_tile(n, T, Dout, Din):
+    """dW_g = dY_g^T X (grouped, batched split-K) with 256-row output tiles."""
+    hip, emu = calm.backend.get_backend(), EmulatedBackend()
+    x = rnd(T, Din, seed=1)
+    dys = [rnd(T, Dout, seed=20 + g) for g in range(n)]
+    G_ref = [torch.zeros(Dout, Din) for _ in range(n)]
+    G_hip = [torch.full((Dout, Din), 9.0).cuda() for _ in range(n)]
+    args = (Dout, Din, T, (1, Dout, 0, 0), (1, Din, 0, 0), (Din, 0, 0))
+    calm.backend.set_matmul_precision("bf16")
+    emu.gemm(dys, x, G_ref, *args, batch=(n, 1))
+    hip.gemm([d.cuda() for d in dys], x.cuda(), G_hip, *args, batch=(n, 1))
+    for g in range(n):
+        assert rel_err(G_hip[g], G_ref[g]) < 2e-4
+
+
 @pytest.mark.parametrize("prec", ["bf16", "bf16x3"])
 def test_split_k_weight_gradient_in_bf16_modes(prec):
     hip, emu = calm.backend.get_backend(), EmulatedBackend()
