@@ -893,8 +893,8 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     if (a->dtype != CALM_F32 && a->dtype != CALM_BF16 && a->dtype != CALM_BF16X3) return CALM_E_UNSUPP;
     if (a->a_rs != 1 && a->a_cs != 1) return CALM_E_LAYOUT;
     if (a->b_rs != 1 && a->b_cs != 1) return CALM_E_LAYOUT;
-    // the staging cursors address a tile with 32-bit byte offsets from a per-tile base
-    if (a->a_rs >= (1 << 22) || a->a_cs >= (1 << 22) || a->b_rs >= (1 << 22) || a->b_cs >= (1 << 22)) return CALM_E_UNSUPP;
+    // the staging cursors address a tile with 32-bit byte offsets from a per-tile base: 255 rows x stride x 4 B < 2^32
+    if (a->a_rs >= (1 << 21) || a->a_cs >= (1 << 21) || a->b_rs >= (1 << 21) || a->b_cs >= (1 << 21)) return CALM_E_UNSUPP;
     if (a->act == CALM_ACT_GELU_BWD && !a->aux) return CALM_E_INVAL;
     if (a->act < 0 || a->act > CALM_ACT_GELU_BWD) return CALM_E_INVAL;
     if (a->n_group < 0 || a->n_group > CALM_GEMM_MAX_GROUP) return CALM_E_INVAL;

@@ -55,6 +55,8 @@ const char* calm_build_info(void);     /* "gfx950 ..." */
  *   C(m,n)    = y * (col_scale ? col_scale[n] : 1) + (residual ? residual(m,n) : 0) [+ C(m,n) if accumulate]
  *
  * One of (a_rs, a_cs) must be 1, likewise (b_rs, b_cs); C is n-contiguous.
+ * Operand row / column strides must be below 2^21 elements (CALM_E_UNSUPP otherwise): a tile is addressed with
+ * 32-bit byte offsets from a per-tile base.
  * batch = batch0*batch1 independent problems (b0,b1 strides per operand; 0 = broadcast).
  * reduce_batch: all batches are summed into ONE C (c_b0/c_b1 ignored) — the weight gradient of
  * the sequence-axis linears.  split_k: 0 = library picks, 1 = off, >1 = that many K-slices; slices

@@ -150,6 +150,8 @@ def test_gemm_rejects_bad_arguments(hip):
         hip.gemm(A, A, A, 0, 8, 8, (8, 1, 0, 0), (8, 1, 0, 0), (8, 0, 0))       # empty problem
     with pytest.raises(RuntimeError):
         hip.gemm(A.cpu(), A, A, 8, 8, 8, (8, 1, 0, 0), (8, 1, 0, 0), (8, 0, 0))  # CPU tensor
+    with pytest.raises(RuntimeError):
+        hip.gemm(A, A, A, 8, 8, 8, (1 << 21, 1, 0, 0), (8, 1, 0, 0), (8, 0, 0))  # row stride beyond the 32-bit tile offsets
 
 
 @pytest.mark.parametrize("rows,D", [(37, 144), (1000, 672), (5, 36), (64, 1152), (2500, 528), (300, 240),
