@@ -260,11 +260,12 @@ def test_reference_amp_step_with_grad_scaler():
     assert all(l == l for l in losses) and losses[-1] < losses[0], losses
 
 
-@pytest.mark.parametrize("prec,tol", [("bf16", 2e-4), ("bf16x3", 5e-5)])
-def test_grouped_projection_gemm_on_the_bf16_pipe(prec, tol):
+@pytest.mark.parametrize("prec,tol,M,D", [("bf16", 2e-4, 520, 96), ("bf16x3", 5e-5, 520, 96),
+                                          ("bf16", 2e-4, 65540, 256)])     # last: enough 256x128 tiles for the wide kernel
+def test_grouped_projection_gemm_on_the_bf16_pipe(prec, tol, M, D):
     """Grouped q/k/v launch and its one-pass input gradient (per-group sigma) in the bf16-operand families."""
     hip, emu = calm.backend.get_backend(), EmulatedBackend()
-    n, M, D = 3, 520, 96
+    n = 3
     x = rnd(M, D, seed=1)
     ws = [rnd(D, D, seed=10 + g) / 8 for g in range(n)]
     sig = [torch.tensor([0.7 + 0.4 * g]) for g in range(n)]
