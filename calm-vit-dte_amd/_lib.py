@@ -35,6 +35,7 @@ class GemmArgs(C.Structure):
         ("act", _i32), ("accumulate", _i32), ("reduce_batch", _i32), ("split_k", _i32), ("dtype", _i32),
         ("n_group", _i32),
         ("A_group", _p * 4), ("B_group", _p * 4), ("C_group", _p * 4), ("inv_scale_group", _p * 4),
+        ("workspace", _p), ("workspace_bytes", _i64),
     ]
 
 
@@ -65,6 +66,7 @@ SIGNATURES = {
     "calm_abi_version": (_i32, []),
     "calm_build_info": (C.c_char_p, []),
     "calm_gemm": (_i32, [C.POINTER(GemmArgs), _p]),
+    "calm_gemm_workspace_bytes": (_i64, [C.POINTER(GemmArgs)]),
     "calm_layernorm_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _f32, _p]),
     "calm_layernorm_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "calm_rope_fwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
@@ -117,7 +119,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.calm_abi_version() != 2:
+    if lib.calm_abi_version() != 3:
         raise RuntimeError("libcalmvit_hip.so ABI version mismatch")
     _lib = lib
     return lib

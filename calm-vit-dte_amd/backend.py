@@ -9,6 +9,7 @@ in the package ever installs another backend.
 """
 import contextlib
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -19,6 +20,7 @@ from ._lib import ACT_GELU, ACT_GELU_BWD, ACT_NONE  # noqa: F401  (re-exported)
 SN_EPS = 1e-12
 
 # calm_gemm_args.dtype (include/calm_vit.h): which matrix pipe the GEMMs use.  Tensors are fp32 in every mode.
+GEMM_WORKSPACE = os.environ.get("CALM_GEMM_WORKSPACE", "1") != "0"      # A/B switch: 0 = split launches always use atomics
 PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
 _precision = "fp32"
 
@@ -152,6 +154,14 @@ class HipBackend:
         g.reduce_batch = int(reduce_batch)
         g.split_k = split_k
         g.dtype = PRECISIONS[effective_precision()]
+        ws = None
+        if split_k != 1 and GEMM_WORKSPACE:
+            # split launches with many k-slices per output combine them through a workspace instead of atomics; the
+            # buffer comes from torch's caching allocator and is stream-ordered like every other tensor of the step
+            need = self.lib.calm_gemm_workspace_bytes(C.byref(g))
+            if need > 0:
+                ws = torch.empty(need // 4, dtype=torch.float32, device=Cout.device)
+                g.workspace, g.workspace_bytes = ws.data_ptr(), need
         _lib.check(self.lib.calm_gemm(C.byref(g), _stream()), "calm_gemm")
 
     # ---- device-side collate -------------------------------------------------------------

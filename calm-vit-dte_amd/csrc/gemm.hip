@@ -42,6 +42,7 @@ struct GemmP {
     int slices_per_batch;          // batched split-K: k-slices per batch entry (0: off)
     int n_group, reduce_group;     // reduce_group: the groups are summed into one C
     const float* Ag[4]; const float* Bg[4]; float* Cg[4]; const float* Sg[4];
+    float* ws; long ws_slice;      // split launches with a workspace: slice blockIdx.y stores its partial tile at ws + y * ws_slice
 };
 
 // operand base of batch entry (b0, b1)
@@ -244,6 +245,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
             const float sj = p.col_scale ? p.col_scale[col] : 1.f;
             const int row0 = m0 + wm * (32 * MT) + 32 * i + 4 * h;
             if (p.atomic) {
+                if (p.ws) {                      // dense [M][N] partial of this k-slice; splitk_reduce sums the slices
+                    float* __restrict__ Wb = p.ws + (long)blockIdx.y * p.ws_slice;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = row0 + (e & 3) + 8 * (e >> 2);
+                        if (row < p.M) Wb[(long)row * p.N + col] = a[e] * scale;
+                    }
+                    return;
+                }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = row0 + (e & 3) + 8 * (e >> 2);
@@ -883,11 +893,42 @@ int launch(const GemmP& p, dim3 grid, int bn, hipStream_t s) {
     return 0;
 }
 
+// Second pass of a split launch with a workspace: C[m][n] (+= if accumulate) sum over the slices' partial tiles.
+// grid.y = output (group); outputs are Cg[y] when given, else C + y * c_b0.
+struct ReduceP {
+    const float* ws; long ws_slice; int nslices;
+    float* C; float* Cg[4]; long c_b0, c_rs;
+    int M, N, accumulate;
+};
+__global__ __launch_bounds__(256) void splitk_reduce(const ReduceP q) {
+    const long total = (long)q.M * q.N;
+    const float* w = q.ws + (long)blockIdx.y * q.nslices * q.ws_slice;
+    float* out = q.Cg[0] ? q.Cg[blockIdx.y] : q.C + blockIdx.y * q.c_b0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        float s0 = 0.f, s1 = 0.f;
+        int sl = 0;
+        for (; sl + 1 < q.nslices; sl += 2) {
+            s0 += w[(long)sl * q.ws_slice + i];
+            s1 += w[(long)(sl + 1) * q.ws_slice + i];
+        }
+        if (sl < q.nslices) s0 += w[(long)sl * q.ws_slice + i];
+        const unsigned m = (unsigned)i / (unsigned)q.N, n = (unsigned)i - m * (unsigned)q.N;
+        float* dst = out + (long)m * q.c_rs + n;
+        *dst = (q.accumulate ? *dst : 0.f) + s0 + s1;
+    }
+}
+
 inline bool mult4(int64_t x) { return (x & 3) == 0; }
 
 }  // namespace
 
-extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
+#ifndef CALM_GEMM_WS_MIN_SLICES
+#define CALM_GEMM_WS_MIN_SLICES 48     // per-slice partial tiles + one reduction instead of atomics from this many k-slices
+#endif                                 // per output (A/B with plain stores in place of the atomics: outputs of 528 rows and
+                                       // more, <= 42 slices, do not change; 384x768 ... 240x240, 53-106 slices, -15..-30%)
+
+// query != nullptr: plan only and report the workspace size of the launch (calm_gemm_workspace_bytes)
+static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
     if (!a || !a->A || !a->B || !a->C) return CALM_E_INVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch0 <= 0 || a->batch1 <= 0) return CALM_E_INVAL;
     if (a->dtype != CALM_F32 && a->dtype != CALM_BF16 && a->dtype != CALM_BF16X3) return CALM_E_UNSUPP;
@@ -1026,23 +1067,10 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     }
     if (p.slices_per_batch) {
         p.kb_per_z = (p.kpb + nsplit - 1) / nsplit;
-        if (!a->accumulate) {
-            for (int g = 0; g < a->n_group; ++g) {
-                hipError_t e;
-                if (a->c_rs == a->N) e = hipMemsetAsync(p.Cg[g], 0, sizeof(float) * (size_t)a->M * a->N, s);
-                else e = hipMemset2DAsync(p.Cg[g], sizeof(float) * a->c_rs, 0, sizeof(float) * a->N, a->M, s);
-                if (e != hipSuccess) return (int)e;
-            }
-        }
+        p.slices_per_batch = (p.kpb + p.kb_per_z - 1) / p.kb_per_z;      // no empty trailing slices
     } else if (p.atomic) {
         if (!trivial_epi) return CALM_E_UNSUPP;
         p.kb_per_z = (p.kb_total + nsplit - 1) / nsplit;
-        if (!a->accumulate) {
-            hipError_t e;
-            if (a->c_rs == a->N) e = hipMemsetAsync(p.C, 0, sizeof(float) * (size_t)a->M * a->N, s);
-            else e = hipMemset2DAsync(p.C, sizeof(float) * a->c_rs, 0, sizeof(float) * a->N, a->M, s);
-            if (e != hipSuccess) return (int)e;
-        }
     } else if (grouped_reduce_unsplit) {
         p.kb_per_z = p.kb_total;                            // grid.y == 1
     } else {
@@ -1052,17 +1080,65 @@ extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) {
     if (gy > 65535) return CALM_E_UNSUPP;
     dim3 grid(tiles, gy);
 
-    if (wide) return launch_wide(p, grid, akc, bkc, s);
-    if (family == CALM_BF16) return launch_c_layout<1>(p, grid, bn, akc, bkc, s);
-    if (family == CALM_BF16X3) return launch_c_layout<3>(p, grid, bn, akc, bkc, s);
-    if (vec) {
-        if (akc && bkc) return launch<true, true, 4>(p, grid, bn, s);
-        if (akc && !bkc) return launch<true, false, 4>(p, grid, bn, s);
-        if (!akc && bkc) return launch<false, true, 4>(p, grid, bn, s);
-        return launch<false, false, 4>(p, grid, bn, s);
+    // how the k-slices are combined: fp32 atomics onto a zeroed (or accumulated-into) C, or — many slices per output
+    // and a caller-provided workspace — one dense partial tile per slice and a reduction pass
+    const int n_out = p.slices_per_batch ? batch : 1;
+    const int slices_per_out = gy / n_out;
+    p.ws = nullptr;
+    p.ws_slice = (long)a->M * a->N;
+    int64_t ws_need = 0;
+    if (p.atomic && slices_per_out >= CALM_GEMM_WS_MIN_SLICES && p.ws_slice >= 100000)     // tiny outputs: the second launch costs more than their atomics
+        ws_need = (int64_t)sizeof(float) * gy * p.ws_slice;
+    if (query) {
+        *query = ws_need;
+        return 0;
     }
-    if (akc && bkc) return launch<true, true, 1>(p, grid, bn, s);
-    if (akc && !bkc) return launch<true, false, 1>(p, grid, bn, s);
-    if (!akc && bkc) return launch<false, true, 1>(p, grid, bn, s);
-    return launch<false, false, 1>(p, grid, bn, s);
+    const bool use_ws = ws_need > 0 && a->workspace && a->workspace_bytes >= ws_need && aligned16(a->workspace);
+    if (use_ws) {
+        p.ws = (float*)a->workspace;
+    } else if (p.atomic && !a->accumulate) {
+        for (int g = 0; g < n_out; ++g) {
+            float* out = p.slices_per_batch ? p.Cg[g] : p.C;
+            hipError_t e;
+            if (a->c_rs == a->N) e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)a->M * a->N, s);
+            else e = hipMemset2DAsync(out, sizeof(float) * a->c_rs, 0, sizeof(float) * a->N, a->M, s);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+
+    auto launch_main = [&]() -> int {
+        if (wide) return launch_wide(p, grid, akc, bkc, s);
+        if (family == CALM_BF16) return launch_c_layout<1>(p, grid, bn, akc, bkc, s);
+        if (family == CALM_BF16X3) return launch_c_layout<3>(p, grid, bn, akc, bkc, s);
+        if (vec) {
+            if (akc && bkc) return launch<true, true, 4>(p, grid, bn, s);
+            if (akc && !bkc) return launch<true, false, 4>(p, grid, bn, s);
+            if (!akc && bkc) return launch<false, true, 4>(p, grid, bn, s);
+            return launch<false, false, 4>(p, grid, bn, s);
+        }
+        if (akc && bkc) return launch<true, true, 1>(p, grid, bn, s);
+        if (akc && !bkc) return launch<true, false, 1>(p, grid, bn, s);
+        if (!akc && bkc) return launch<false, true, 1>(p, grid, bn, s);
+        return launch<false, false, 1>(p, grid, bn, s);
+    };
+    const int rc = launch_main();
+    if (rc || !use_ws) return rc;
+
+    ReduceP q;
+    q.ws = p.ws; q.ws_slice = p.ws_slice; q.nslices = slices_per_out;
+    q.C = p.C; q.c_b0 = a->c_b0; q.c_rs = a->c_rs;
+    for (int g = 0; g < 4; ++g) q.Cg[g] = p.slices_per_batch ? p.Cg[g] : nullptr;
+    q.M = a->M; q.N = a->N; q.accumulate = a->accumulate;
+    const long total = (long)a->M * a->N;
+    const int gx = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce, dim3(gx, n_out), dim3(256), 0, s, q);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) { return gemm_run(a, stream, nullptr); }
+
+extern "C" int64_t calm_gemm_workspace_bytes(const calm_gemm_args* a) {
+    int64_t bytes = 0;
+    return gemm_run(a, nullptr, &bytes) == 0 ? bytes : 0;
 }

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CALM_ABI_VERSION 2
+#define CALM_ABI_VERSION 3
 
 #define CALM_E_INVAL   (-1)   /* null pointer / negative size                 */
 #define CALM_E_LAYOUT  (-2)   /* stride pattern the kernel cannot address     */
@@ -99,10 +99,17 @@ typedef struct calm_gemm_args {
     const void*  B_group[4];
     void*        C_group[4];
     const float* inv_scale_group[4];
+    void*        workspace;      /* optional (ABI v3): device scratch for split launches, see calm_gemm_workspace_bytes */
+    int64_t      workspace_bytes;
 } calm_gemm_args;
 #define CALM_GEMM_MAX_GROUP 4
 
 int calm_gemm(const calm_gemm_args* args, void* stream);
+/* Bytes of `workspace` with which this launch would combine its k-slices through per-slice partial tiles and one
+ * reduction pass instead of fp32 atomics (0: the launch is not split, or atomics are as fast — large outputs).
+ * Passing less (or NULL) is always valid: the launch then uses atomics.  The caller owns the buffer; it is only used
+ * until the launch's kernels have run on `stream`. */
+int64_t calm_gemm_workspace_bytes(const calm_gemm_args* args);
 
 /* ---------------------------------------------------------------------------------------
  * LayerNorm(D, eps, bias=False) over the last axis (Vi_Tools:131-132,197,494; fwd 211-215,311,523).

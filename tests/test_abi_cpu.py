@@ -14,7 +14,7 @@ LIB = os.path.join(ROOT, "calm-vit-dte_amd", "libcalmvit_hip.so")
 def _declared():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"^\s*(?:int|int32_t|const char\*)\s+(calm_\w+)\s*\(", text, flags=re.M)))
+    return sorted(set(re.findall(r"^\s*(?:int|int32_t|int64_t|const char\*)\s+(calm_\w+)\s*\(", text, flags=re.M)))
 
 
 def _library():

@@ -34,7 +34,7 @@ def rnd(*shape, seed=0, scale=1.0):
 
 
 def test_library_loads_and_reports_gfx950(hip):
-    assert hip.lib.calm_abi_version() == 2
+    assert hip.lib.calm_abi_version() == 3
     assert b"gfx950" in hip.lib.calm_build_info()
 
 
@@ -116,6 +116,62 @@ def test_gemm_split_k_weight_gradient(hip, emu, M, N, K):
     emu.gemm(dy, x, G_ref, *args)
     hip.gemm(dy.cuda(), x.cuda(), G_hip, *args)
     assert rel_err(G_hip, G_ref) < TOL
+
+
+def test_gemm_small_split_k_outputs_ask_for_no_workspace(hip):
+    """Below ~100k output elements the second launch costs more than the atomics: the query says 0."""
+    import ctypes as C
+    from importlib import import_module
+    binding = import_module("calm_vit_dte_amd._lib")
+    for (M, N, K), expect in (((80, 160, 20480), False), ((264, 120, 45056), False), ((384, 384, 32768), True),
+                              ((672, 672, 57344), False)):             # last: large output, few slices
+        dy, x, G = torch.zeros(K, M).cuda(), torch.zeros(K, N).cuda(), torch.zeros(M, N).cuda()
+        g = binding.GemmArgs()
+        g.A, g.B, g.C = dy.data_ptr(), x.data_ptr(), G.data_ptr()
+        g.M, g.N, g.K, g.batch0, g.batch1 = M, N, K, 1, 1
+        g.a_rs, g.a_cs, g.b_rs, g.b_cs, g.c_rs = 1, M, 1, N, N
+        g.alpha = 1.0
+        assert (hip.lib.calm_gemm_workspace_bytes(C.byref(g)) > 0) == expect, (M, N, K)
+
+
+@pytest.mark.parametrize("M,N,K,acc", [(384, 384, 32768, False), (240, 480, 20480, True), (384, 768, 32768, False)])
+def test_gemm_split_k_through_the_workspace(hip, emu, monkeypatch, M, N, K, acc):
+    """Mid-sized weight gradients (>= 48 k-slices per output): the slices' partial tiles go to a caller-owned workspace
+    and one reduction pass writes C (strided rows, optional accumulate) — deterministic, unlike the atomics it replaces;
+    without a workspace the same call falls back to atomics."""
+    import ctypes
+    dy, x = rnd(K, M, seed=1), rnd(K, N, seed=2)
+    ld = N + 8                                                   # output rows strided: the 8 pad columns must survive
+    base = rnd(M, ld, seed=3)
+    args = (M, N, K, (1, M, 0, 0), (1, N, 0, 0), (ld, 0, 0))
+    G_ref = base.clone()
+    if not acc:
+        G_ref[:, :N] = 0
+    emu.gemm(dy, x, G_ref, *args, accumulate=True)
+    dyc, xc = dy.cuda(), x.cuda()
+
+    asked = []
+    real_query = hip.lib.calm_gemm_workspace_bytes
+    def query(a):
+        asked.append(real_query(a))
+        return asked[-1]
+    monkeypatch.setattr(hip.lib, "calm_gemm_workspace_bytes", query)
+    outs = []
+    for _ in range(2):
+        G = base.cuda()
+        hip.gemm(dyc, xc, G, *args, accumulate=acc)
+        outs.append(G)
+    assert asked and all(b > 0 and b % (4 * M * N) == 0 for b in asked)      # whole partial tiles, >= 48 of them
+    assert asked[0] // (4 * M * N) >= 48
+    assert rel_err(outs[0][:, :N], G_ref[:, :N]) < TOL
+    assert torch.equal(outs[0], outs[1])                                      # no atomics: bit-reproducible
+    assert torch.equal(outs[0][:, N:].cpu(), base[:, N:])
+
+    monkeypatch.setattr(hip.lib, "calm_gemm_workspace_bytes", lambda a: 0)    # no workspace offered: atomics
+    G = base.cuda()
+    hip.gemm(dyc, xc, G, *args, accumulate=acc)
+    assert rel_err(G[:, :N], G_ref[:, :N]) < TOL
+    assert torch.equal(G[:, N:].cpu(), base[:, N:])
 
 
 @pytest.mark.parametrize("akc,bkc", [(True, True), (True, False), (False, True), (False, False)])
