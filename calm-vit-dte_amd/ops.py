@@ -8,6 +8,7 @@ never materialised by a transpose).
 """
 import math
 import os
+import threading
 
 import torch
 from torch.autograd import Function
@@ -42,6 +43,35 @@ def draw_noise(like):
 
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+class _ZeroArena:
+    """Small zero-initialised gradient accumulators (LayerNorm dw, bias column sums, RoPE d_inv_freq, the CNN tail's
+    weight gradients: ~200 per step, each a few hundred floats) are handed out as slices of 1 MB chunks that one
+    fill kernel zeroes, instead of one torch.zeros launch each.  Chunks are never reset or reused: a chunk lives as
+    long as any slice of it (a .grad) does, so there is no aliasing between steps."""
+    CHUNK = 1 << 18          # floats
+
+    def __init__(self):
+        self.buf, self.off, self.lock = None, 0, threading.Lock()
+
+    def take(self, shape, like):
+        n = int(math.prod(shape))
+        m = (n + 63) & ~63                                   # 256-byte granules
+        capturing = like.is_cuda and torch.cuda.is_current_stream_capturing()
+        if not ZERO_ARENA or m > self.CHUNK // 4 or like.dtype != torch.float32 or capturing:
+            return torch.zeros(shape, dtype=like.dtype, device=like.device)
+        with self.lock:
+            if self.buf is None or self.buf.device != like.device or self.off + m > self.CHUNK:
+                self.buf = torch.zeros(self.CHUNK, dtype=torch.float32, device=like.device)
+                self.off = 0
+            v = self.buf[self.off:self.off + n].view(shape)
+            self.off += m
+        return v
+
+
+ZERO_ARENA = os.environ.get("CALM_ZERO_ARENA", "1") != "0"      # A/B switch
+_zeros = _ZeroArena().take
 
 
 # ---------------------------------------------------------------------------------------
@@ -90,7 +120,7 @@ def _sn_wbwd(be, G, w, u, v, sigma, ls=None):
 
 
 def _colsum(be, x2):
-    out = torch.zeros(x2.shape[1], dtype=x2.dtype, device=x2.device)
+    out = _zeros((x2.shape[1],), x2)
     be.colsum(x2, out, x2.shape[0], x2.shape[1])
     return out
 
@@ -122,7 +152,7 @@ class LayerNormFn(Function):
         dy = _c(dy)
         D = x.shape[-1]
         dx = torch.empty_like(x)
-        dw = torch.zeros_like(w)
+        dw = _zeros(w.shape, w)
         be.layernorm_bwd(dy, x, w, mean, rstd, dx, dw, x.numel() // D, D)
         return dx, dw, None
 
@@ -159,7 +189,7 @@ class LayerNormSkipFn(Function):
         dy = _c(dy)
         D = x.shape[-1]
         dx = torch.empty_like(x)
-        dw = torch.zeros_like(w)
+        dw = _zeros(w.shape, w)
         be.layernorm_bwd(dy, x, w, mean, rstd, dx, dw, x.numel() // D, D,
                          dx_add=_c(dskip).reshape(x.shape) if dskip is not None else None)
         return dx, dw, None
@@ -400,7 +430,7 @@ class RopeFn(Function):
         dout = _c(dout)
         d_xr = torch.empty_like(xr)
         d_content = torch.empty(B, S, H * dc, dtype=xr.dtype, device=xr.device) if dc > 0 else None
-        d_if = torch.zeros(dr // 2, dtype=xr.dtype, device=xr.device)
+        d_if = _zeros((dr // 2,), xr)
         be.rope_bwd(dout, xr, table, d_content, d_xr, d_if, B, S, H, dc, dr)
         return d_content, d_xr, d_if, None
 
@@ -658,7 +688,7 @@ class CnnResidualFn(Function):
         dy = _c(dy)
         dev, dt = dy.device, dy.dtype
         dx = torch.empty_like(dy)
-        gall = torch.zeros(Ch * 3 + Ch + Ch * 9 + Ch + 3 * Ch + 3, dtype=dt, device=dev)
+        gall = _zeros((Ch * 3 + Ch + Ch * 9 + Ch + 3 * Ch + 3,), dy)
         G0, db0, G2, db2, G4, db4 = torch.split(gall, [Ch * 3, Ch, Ch * 9, Ch, 3 * Ch, 3])
         be.cnn_bwd(dy, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, dx, G0, db0, G2, db2, G4, db4, B, S, Ch)
         dW0, _ = _sn_wbwd(be, G0.view(Ch, 3), w0.view(Ch, 3), u0, v0, s0)
