@@ -50,9 +50,8 @@ class _ZeroArena:
     weight gradients: ~200 per step, each a few hundred floats) are handed out as slices of 1 MB chunks that one
     fill kernel zeroes, instead of one torch.zeros launch each.  Chunks are never reset or reused: a chunk lives as
     long as any slice of it (a .grad) does, so there is no aliasing between steps."""
-    CHUNK = 1 << 18          # floats
-
-    def __init__(self):
+    def __init__(self, chunk_floats=1 << 18):
+        self.CHUNK = chunk_floats
         self.buf, self.off, self.lock = None, 0, threading.Lock()
 
     def take(self, shape, like):
@@ -72,6 +71,9 @@ class _ZeroArena:
 
 ZERO_ARENA = os.environ.get("CALM_ZERO_ARENA", "1") != "0"      # A/B switch
 _zeros = _ZeroArena().take
+# weight-gradient outputs of the split-K launches (up to a few MB each, ~160 MB per step): slices of 64 MB zeroed
+# chunks + accumulate=True, so that calm_gemm needs no memset per output
+_zeros_big = _ZeroArena(1 << 24).take
 
 
 # ---------------------------------------------------------------------------------------
@@ -96,7 +98,7 @@ def _lin_wgrad(be, dy2, x2, G):
     only non-bitwise-reproducible launches of the path; forward and dgrad GEMMs never split)."""
     M, N = dy2.shape
     K = x2.shape[1]
-    be.gemm(dy2, x2, G, N, K, M, (1, N, 0, 0), (1, K, 0, 0), (K, 0, 0))
+    be.gemm(dy2, x2, G, N, K, M, (1, N, 0, 0), (1, K, 0, 0), (K, 0, 0), accumulate=True)     # G comes zeroed (_zeros_big)
 
 
 # sigma.data_ptr() of the spectral-normed layers whose weight-gradient correction is applied later, by the fused
@@ -232,7 +234,7 @@ class SNLinearFn(Function):
             be.gelu_bwd(dy2, pre.view(-1, N), dz, dy2.numel())
         else:
             dz = dy2
-        G = torch.empty_like(w)
+        G = _zeros_big(w.shape, w)
         _lin_wgrad(be, dz, x2, G)
         dW, d_ls = _sn_wbwd(be, G, w, u, v, sigma, ls)
         dx = None
@@ -289,8 +291,8 @@ class SNLinearGroupFn(Function):
         M = x2.shape[0]
         dy2 = [_c(d).reshape(-1, N) for d in dys]
         # weight gradients G_g = dy_g^T x: one grouped launch, every group split over its own k-slices
-        Gs = [torch.empty_like(w) for w in ws]
-        be.gemm(dy2, x2, Gs, N, K, M, (1, N, 0, 0), (1, K, 0, 0), (K, 0, 0), batch=(n, 1))
+        Gs = [_zeros_big(w.shape, w) for w in ws]
+        be.gemm(dy2, x2, Gs, N, K, M, (1, N, 0, 0), (1, K, 0, 0), (K, 0, 0), batch=(n, 1), accumulate=True)
         grads = []
         for g in range(n):
             grads += [_sn_wbwd(be, Gs[g], ws[g], us[g], vs[g], sigmas[g])[0], None, None, None]
@@ -337,7 +339,7 @@ class MlpFn(Function):
         N, Hd = w2.shape
         K = w1.shape[1]
         do2 = _c(dout).reshape(-1, N)
-        G2 = torch.empty_like(w2)
+        G2 = _zeros_big(w2.shape, w2)
         _lin_wgrad(be, do2, hg, G2)
         dW2, d_ls = _sn_wbwd(be, G2, w2, u2, v2, s2, ls)
         db2 = _colsum(be, do2) if ctx.has_b2 else None
@@ -348,7 +350,7 @@ class MlpFn(Function):
             w2l = w2
         dhp = torch.empty_like(hp)
         _lin_dgrad(be, do2, w2l, s2, dhp, act=ACT_GELU_BWD, aux=hp)
-        G1 = torch.empty_like(w1)
+        G1 = _zeros_big(w1.shape, w1)
         _lin_wgrad(be, dhp, x2, G1)
         dW1, _ = _sn_wbwd(be, G1, w1, u1, v1, s1)
         db1 = _colsum(be, dhp) if ctx.has_b1 else None
@@ -393,8 +395,9 @@ class SeqLinearFn(Function):
             be.gemm(w, dy, dx, S, D, S2, (1, S, 0, 0), (1, D, S2 * D, 0), (D, S * D, 0), batch=(B, 1),
                     inv_scale=sigma)
         # G[s2,s] = sum_b sum_d dY[b,s2,d] X[b,s,d]
-        G = torch.empty_like(w)
-        be.gemm(dy, x, G, S2, S, D, (D, 1, S2 * D, 0), (D, 1, S * D, 0), (S, 0, 0), batch=(B, 1), reduce_batch=True)
+        G = _zeros_big(w.shape, w)
+        be.gemm(dy, x, G, S2, S, D, (D, 1, S2 * D, 0), (D, 1, S * D, 0), (S, 0, 0), batch=(B, 1), reduce_batch=True,
+                accumulate=True)
         dW, _ = _sn_wbwd(be, G, w, u, v, sigma)
         return dx, dW, None, None, None
 
@@ -505,14 +508,14 @@ class LatentMaskAttentionFn(Function):
             be.gemm(dP, q, dk, Skv, hd, Sq, (1, Skv) + pb, (1, D, Sq * D, hd), (D, Skv * D, hd), batch=(B, H),
                     alpha=scale)
         # mask MLP backward
-        G2 = torch.empty_like(w2)
+        G2 = _zeros_big(w2.shape, w2)
         _lin_wgrad(be, dM, hg, G2)
         dW2, _ = _sn_wbwd(be, G2, w2, u2, v2, s2)
         db2 = _colsum(be, dM)
         dhp = torch.empty_like(hp)
         _lin_dgrad(be, dM, w2, s2, dhp, act=ACT_GELU_BWD, aux=hp)
         R2 = R.view(B * Sq, Skv)
-        G1 = torch.empty_like(w1)
+        G1 = _zeros_big(w1.shape, w1)
         _lin_wgrad(be, dhp, R2, G1)
         dW1, _ = _sn_wbwd(be, G1, w1, u1, v1, s1)
         db1 = _colsum(be, dhp)
