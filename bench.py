@@ -24,9 +24,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
-    if p not in sys.path:
-        sys.path.insert(0, p)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -71,7 +70,7 @@ def synthetic_batch(batch, S, classes, seed, device):
 
 
 def build_model(calm, kw, device):
-    import weights as W
+    W = calm.synthetic_weights
     m = calm.ViT(torch.device("cpu"), type=8, force_reduce=False, generate=False, **kw)
     shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
     m.load_state_dict({k: torch.from_numpy(v) for k, v in W.make_params(shapes, WEIGHT_SEED).items()})
@@ -148,7 +147,8 @@ def pmc_traffic(kernel_prefix):
 def cpu_baseline(wl, budget_s=15.0):
     """CPU oracle (port of the reference path) fwd+bwd+AdamW on a bounded sample of the workload."""
     from oracle import calm_oracle as O
-    import weights as W
+    import calm_vit_dte_amd as calm
+    W = calm.synthetic_weights
     threads = max(1, min(len(os.sched_getaffinity(0)), 16))
     torch.set_num_threads(threads)
     cfg = O.ViTConfig(force_reduce=False, generate=False, **wl["kw"])
@@ -181,6 +181,23 @@ def cpu_baseline(wl, budget_s=15.0):
             "sample": f"oracle fwd+bwd+AdamW fp32, bs={bs}, {len(times)} timed steps after 1 warm-up, median"}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without an external launcher: BEFORE anything touches the GPU, start N fresh ranks
+    under torch.distributed.run (env:// rendezvous on 127.0.0.1, one process per GPU), relay rank 0's JSON line and
+    return the launcher's exit status.  (Never re-exec a process that has initialised the GPU.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -202,6 +219,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gemm-report", default="", help="write a per-shape GEMM table (csv) from the profiled steps")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     import calm_vit_dte_amd as calm
     from importlib import import_module
@@ -295,8 +314,12 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": PRECISION_INFO[args.precision][0],
             "data": "synthetic",
             "config": {"workload": f"CALM-ViT {args.workload} cls, {S}x{S}x3 synthetic, bs={batch}/GPU, "
-                                   f"{args.precision} matmuls, fwd+loss+bwd+clip+AdamW", "global_batch": world * batch,
-                       "parallelism": f"dp{world}", "loss": float(loss), "hipgraph": bool(args.graph),
+                                   f"{args.precision} matmuls, fwd+loss+bwd+clip+AdamW; batch resident in HBM when the "
+                                   "timed region starts (the trainer's H2D copy of the batch is excluded)",
+                       "global_batch": world * batch,
+                       "parallelism": f"dp{world}", "world": dist.get_world_size() if dist.is_initialized() else 1,
+                       "backend": dist.get_backend() if dist.is_initialized() else "none (single process)",
+                       "loss": float(loss), "hipgraph": bool(args.graph),
                        "optimizer": "torch clip_grad_norm_ + AdamW" if (args.torch_optim or args.graph)
                        else "calm_optim_step (norm + clip + AdamW + spectral-norm grad correction, 3 launches)"},
             "model_tflops": round(value * wl["gflop_img"] / 1e3, 2),

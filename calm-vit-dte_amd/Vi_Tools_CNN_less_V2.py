@@ -16,8 +16,19 @@ from .spectral_norm import SNConv2d, SNLinear, sn_scope
 
 
 class ResidualStateManager():
-    """Running latent state shared by the reducing blocks (Vi_Tools:7-50); same modes
-    ("sma", "ema", "lp", "sum", else static momentum)."""
+    """Latent state carried from one reducing block to the next (Vi_Tools:7-50): every block folds its sampled
+    (zq, zkv) into the running state and reads the folded state back, and the KL terms of all blocks are summed and
+    averaged over the blocks seen.
+
+    The path only ever builds it with mode="sum" (Vi_Tools:497-499): state += z, on the device through ops.add.  The
+    other modes of the reference's constructor are kept with the same arithmetic, expressed as one rule — the new
+    state is `w_new * z + w_old * state` with per-mode weights — and run as plain tensor expressions (they are not
+    on the accelerated path):
+        "sum", "sma"      w_new = w_old = 1                  ("sma" hands out state / count)
+        "ema"             w_new = smooth_factor / (count + 1)
+        "lp"              w_new = count / (count + 1)
+        anything else     w_new = momentum (fixed)           and w_old = 1 - w_new for these three
+    """
 
     def __init__(self, smooth_factor: float = 2.0, momentum: float = 0.9, mode: str = "ema"):
         super().__init__()
@@ -30,32 +41,37 @@ class ResidualStateManager():
         self.momentum = momentum
 
     @staticmethod
-    def _kl(mean, var):
-        # Vi_Tools:24-25, for callers that did not get the KL term from the fused latent kernel
-        return -0.5 * torch.mean(1 + 2 * torch.log(var) - mean.pow(2) - var.pow(2))
+    def _kl(mean, std):
+        # KL(N(mean, std) || N(0, 1)) averaged over elements (Vi_Tools:24-25; "var" there is the softplus output used
+        # as a standard deviation) — for callers that did not get the term from the fused latent kernel
+        return -0.5 * torch.mean(1 + 2 * torch.log(std) - mean.pow(2) - std.pow(2))
+
+    def _blend_weight(self):
+        """Weight of the incoming sample for the averaging modes, after `count` was advanced."""
+        if self.mode == "ema":
+            self.momentum = self.smooth_factor / (self.count + 1)
+        elif self.mode == "lp":
+            self.momentum = self.count / (self.count + 1)
+        return self.momentum
 
     def get_sums(self, zq, zkv, mean_q, var_q, mean_kv, var_kv, kl_q=None, kl_kv=None):
-        kl_q = self._kl(mean_q, var_q) if kl_q is None else kl_q
-        kl_kv = self._kl(mean_kv, var_kv) if kl_kv is None else kl_kv
+        if kl_q is None:
+            kl_q = self._kl(mean_q, var_q)
+        if kl_kv is None:
+            kl_kv = self._kl(mean_kv, var_kv)
         self.tot_kl_loss = kl_q + kl_kv + self.tot_kl_loss
-        if self.zq_sum is None:
-            self.zq_sum = zq
-            self.zkv_sum = zkv
-            self.count = 1
-        elif self.mode != "sum" and self.mode != "sma":
-            self.count += 1
-            if self.mode == "ema":
-                self.momentum = self.smooth_factor / (self.count + 1)
-            elif self.mode == "lp":
-                self.momentum = self.count / (self.count + 1)
-            self.zq_sum = (self.momentum * zq) + ((1 - self.momentum) * self.zq_sum)
-            self.zkv_sum = (self.momentum * zkv) + ((1 - self.momentum) * self.zkv_sum)
+        first = self.zq_sum is None
+        self.count = 1 if first else self.count + 1
+        if first:
+            self.zq_sum, self.zkv_sum = zq, zkv
+        elif self.mode in ("sum", "sma"):
+            self.zq_sum, self.zkv_sum = ops.add(self.zq_sum, zq), ops.add(self.zkv_sum, zkv)
         else:
-            self.count += 1
-            self.zq_sum = ops.add(self.zq_sum, zq)
-            self.zkv_sum = ops.add(self.zkv_sum, zkv)
-            if self.mode == "sma":
-                return self.zq_sum / self.count, self.zkv_sum / self.count
+            w = self._blend_weight()
+            self.zq_sum = w * zq + (1 - w) * self.zq_sum
+            self.zkv_sum = w * zkv + (1 - w) * self.zkv_sum
+        if self.mode == "sma" and not first:
+            return self.zq_sum / self.count, self.zkv_sum / self.count
         return self.zq_sum, self.zkv_sum
 
     def get_kl_loss(self):

@@ -12,6 +12,7 @@ LIB_PATH = os.environ.get("CALM_VIT_LIB") or os.path.join(HERE, "libcalmvit_hip.
 
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 F32 = 0
+ABI_VERSION = 4          # CALM_ABI_VERSION of include/calm_vit.h
 
 _p = C.c_void_p
 _i32 = C.c_int32
@@ -58,7 +59,8 @@ class SnLayer(C.Structure):
 
 class SnPlanInfo(C.Structure):
     """struct calm_sn_plan_info."""
-    _fields_ = [("blob_bytes", _i64), ("scratch_floats", _i64), ("n_layers", _i32), ("n_work", _i32)]
+    _fields_ = [("blob_bytes", _i64), ("scratch_floats", _i64), ("n_layers", _i32), ("n_work", _i32),
+                ("n_work_a", _i32), ("reserved", _i32)]
 
 
 # name -> (restype, argtypes); every symbol include/calm_vit.h declares
@@ -85,7 +87,7 @@ SIGNATURES = {
     "calm_sn_power_iter": (_i32, [_p, C.POINTER(SnPlanInfo), _i32, _f32, _p, _p]),
     "calm_sn_weight_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p, _p]),
     "calm_optim_chunk_elems": (_i32, []),
-    "calm_optim_step": (_i32, [_p, _i32, _p, _i32, _p, C.POINTER(OptimHparams), _p, _p, _p]),
+    "calm_optim_step": (_i32, [_p, _i32, _p, _i32, _p, C.POINTER(OptimHparams), _p, _p, _p, _p]),
     "calm_collate_mix": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p]),
     "calm_image_to_rows": (_i32, [_p, _p, _i32, _i32, _p]),
     "calm_rows_to_image": (_i32, [_p, _p, _i32, _i32, _p]),
@@ -119,7 +121,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.calm_abi_version() != 3:
+    if lib.calm_abi_version() != ABI_VERSION:
         raise RuntimeError("libcalmvit_hip.so ABI version mismatch")
     _lib = lib
     return lib

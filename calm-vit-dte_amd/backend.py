@@ -70,7 +70,14 @@ def _stream():
 
 
 class OptimPlan:
-    """Device table of calm_optim_tensor records for calm_optim_step; only the gradient pointers change per step."""
+    """Device table of calm_optim_tensor records for calm_optim_step; only the gradient pointers change per step.
+
+    The pointers travel through a RING of pinned staging buffers, each guarded by an event recorded behind its
+    host-to-device copy: an asynchronous copy from pinned memory reads the host bytes when the DMA runs, not when it is
+    enqueued, and the host runs steps ahead of the GPU — a single buffer would be overwritten with the next step's
+    pointers before the copy of this step's has executed.  A step whose gradients sit at the addresses of the previous
+    upload (gradients kept in the all-reduce buckets, `BucketedGradReducer`) uploads nothing."""
+    RING = 4
 
     def __init__(self, be, records):
         chunk = int(be.lib.calm_optim_chunk_elems())
@@ -83,6 +90,8 @@ class OptimPlan:
                 raise TypeError("optimizer-side step expects contiguous parameters")
             e = rec[i]
             e["param"], e["exp_avg"], e["exp_avg_sq"] = _ptr(p), _ptr(r["exp_avg"]), _ptr(r["exp_avg_sq"])
+            if r["exp_avg"].shape != p.shape or r["exp_avg_sq"].shape != p.shape:
+                raise ValueError("optimizer state shape mismatch")
             e["numel"] = p.numel()
             if r["sn"] is not None:
                 u, v, sigma, rows, cols = r["sn"]
@@ -95,9 +104,30 @@ class OptimPlan:
         self.rec = rec
         self.n_chunks = len(chunk_tensor)
         self.chunk_dev = torch.tensor(chunk_tensor, dtype=torch.int32, device=dev)
-        self.host = torch.empty(rec.nbytes, dtype=torch.uint8).pin_memory()
+        self.hosts = [torch.empty(rec.nbytes, dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
+        self.events = [None] * self.RING
+        self.slot = 0
+        self.uploaded = None                    # gradient pointers of the table now (being) copied to table_dev
         self.table_dev = torch.empty(rec.nbytes, dtype=torch.uint8, device=dev)
-        self.scratch = torch.empty(6 * self.n + 4, dtype=torch.float32, device=dev)
+        self.scratch = torch.empty(6 * self.n + 4 + 3 * self.n_chunks, dtype=torch.float32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)      # advanced by the device, not on skipped steps
+        self.param_ptrs = rec["param"].copy()
+
+    def upload(self, grad_ptrs):
+        """Stage this step's gradient pointers (numpy uint64 array) and enqueue their copy on the current stream."""
+        if self.uploaded is not None and np.array_equal(self.uploaded, grad_ptrs):
+            return
+        k = self.slot
+        if self.events[k] is not None:
+            self.events[k].synchronize()        # the copy out of this staging buffer (RING steps ago) has executed
+        self.rec["grad"] = grad_ptrs
+        self.hosts[k].numpy()[:] = self.rec.view(np.uint8).reshape(-1)
+        self.table_dev.copy_(self.hosts[k], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        self.slot = (k + 1) % self.RING
+        self.uploaded = grad_ptrs.copy()
 
 
 class SnPlan:
@@ -182,14 +212,13 @@ class HipBackend:
         return OptimPlan(self, records)
 
     def optim_step(self, plan, grads, hp, grad_scale, stats_out):
-        """hp = (lr, beta1, beta2, eps, weight_decay, max_norm, step); stats_out[2] <- grad norm, found_inf."""
-        plan.rec["grad"] = np.asarray([_ptr(g) for g in grads], dtype=np.uint64)
-        plan.host.numpy()[:] = plan.rec.view(np.uint8).reshape(-1)
-        plan.table_dev.copy_(plan.host, non_blocking=True)
+        """hp = (lr, beta1, beta2, eps, weight_decay, max_norm, step); stats_out[2] <- grad norm, found_inf.
+        The step count used for the bias correction is plan.step_dev (device; not advanced on skipped steps)."""
+        plan.upload(np.asarray([_ptr(g) for g in grads], dtype=np.uint64))
         h = _lib.OptimHparams(*hp)
         _lib.check(self.lib.calm_optim_step(plan.table_dev.data_ptr(), plan.n, plan.chunk_dev.data_ptr(), plan.n_chunks,
                                             _ptr(plan.scratch), C.byref(h), _ptr(grad_scale, True), _ptr(stats_out),
-                                            _stream()), "calm_optim_step")
+                                            plan.step_dev.data_ptr(), _stream()), "calm_optim_step")
 
     # ---- LayerNorm --------------------------------------------------------------------
     def layernorm_fwd(self, x, w, y, mean, rstd, rows, D, eps):

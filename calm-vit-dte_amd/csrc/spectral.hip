@@ -2,9 +2,12 @@
 // ~3 ATen calls per layer per forward: 882 mv + 883 div).
 //
 // Plan blob (built on the host by calm_sn_plan, copied to device memory by the caller):
-//   [SnLayerDev x n_layers][SnWork x n_work]
-// Work item = (layer, row chunk).  Phases (training):
-//   A: t[c]  += sum_{r in chunk} W[r,c] u[r]                (atomics into scratch; W^T u)
+//   [SnLayerDev x n_layers][SnWork x n_work][SnWorkA x n_work_a]
+// Work item of phases B/C = (layer, row chunk); of phase A = (layer, 64-column group).  Phases (training):
+//   A: t[c]   = sum_r W[r,c] u[r]                            (W^T u; a block owns its columns over ALL rows and adds
+//                                                             its four row-interleaved partial sums in a fixed order:
+//                                                             no atomics, so u, v, sigma are bit-reproducible and
+//                                                             identical on every data-parallel rank)
 //   B: v      = t / max(|t|, eps);  s[r] = W[r,:] . v       (every block renormalises t itself)
 //   C: u      = s / max(|s|, eps);  sigma = u . s           (one block per layer)
 // eval: phase B uses the stored v, phase C the stored u (sigma = u . W v, no update).
@@ -21,17 +24,30 @@ struct SnLayerDev {
     long t_off, s_off;     // offsets into scratch (floats)
 };
 struct SnWork { int layer, row0, nrows, first; };
+struct SnWorkA { int layer, col0; };
+constexpr int COLS_PER_WORK_A = 64;
 
-__global__ __launch_bounds__(NT) void sn_phase_a(const SnLayerDev* __restrict__ layers, const SnWork* __restrict__ work,
+__global__ __launch_bounds__(NT) void sn_phase_a(const SnLayerDev* __restrict__ layers, const SnWorkA* __restrict__ work,
                                                  float* __restrict__ scratch) {
-    const SnWork wk = work[blockIdx.x];
+    __shared__ float part[NT / 64][COLS_PER_WORK_A];
+    const SnWorkA wk = work[blockIdx.x];
     const SnLayerDev L = layers[wk.layer];
-    float* t = scratch + L.t_off;
-    for (int c = threadIdx.x; c < L.cols; c += NT) {
-        float s = 0.f;
-        for (int r = wk.row0; r < wk.row0 + wk.nrows; ++r) s += L.w[(long)r * L.cols + c] * L.u[r];
-        atomicAdd(t + c, s);
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6;        // wave g walks rows g, g+4, ... (a 256-byte row segment per load)
+    const int c = min(wk.col0 + lane, L.cols - 1);                  // columns past the end are clamped, not stored
+    const float* wc = L.w + c;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int r = g;
+    for (; r + 12 < L.rows; r += 16) {                              // four independent loads in flight
+        s0 = fmaf(wc[(long)r * L.cols], L.u[r], s0);
+        s1 = fmaf(wc[(long)(r + 4) * L.cols], L.u[r + 4], s1);
+        s2 = fmaf(wc[(long)(r + 8) * L.cols], L.u[r + 8], s2);
+        s3 = fmaf(wc[(long)(r + 12) * L.cols], L.u[r + 12], s3);
     }
+    for (; r < L.rows; r += 4) s0 = fmaf(wc[(long)r * L.cols], L.u[r], s0);
+    part[g][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && wk.col0 + lane < L.cols)
+        scratch[L.t_off + wk.col0 + lane] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
 __global__ __launch_bounds__(NT) void sn_phase_b(const SnLayerDev* __restrict__ layers, const SnWork* __restrict__ work,
@@ -131,24 +147,29 @@ extern "C" {
 
 int calm_sn_plan(const calm_sn_layer* layers, int32_t n, void* blob_host, calm_sn_plan_info* info) {
     if (!layers || n <= 0 || !info) return CALM_E_INVAL;
-    int n_work = 0;
+    int n_work = 0, n_work_a = 0;
     long scratch = 0;
     for (int i = 0; i < n; ++i) {
         if (!layers[i].w || !layers[i].u || !layers[i].v || !layers[i].sigma || layers[i].rows <= 0 ||
             layers[i].cols <= 0)
             return CALM_E_INVAL;
         n_work += (layers[i].rows + ROWS_PER_WORK - 1) / ROWS_PER_WORK;
+        n_work_a += (layers[i].cols + COLS_PER_WORK_A - 1) / COLS_PER_WORK_A;
         scratch += layers[i].rows + layers[i].cols;
     }
     info->n_layers = n;
     info->n_work = n_work;
+    info->n_work_a = n_work_a;
+    info->reserved = 0;
     info->scratch_floats = scratch;
-    info->blob_bytes = (int64_t)sizeof(SnLayerDev) * n + (int64_t)sizeof(SnWork) * n_work;
+    info->blob_bytes = (int64_t)sizeof(SnLayerDev) * n + (int64_t)sizeof(SnWork) * n_work +
+                       (int64_t)sizeof(SnWorkA) * n_work_a;
     if (!blob_host) return 0;
     SnLayerDev* L = reinterpret_cast<SnLayerDev*>(blob_host);
     SnWork* W = reinterpret_cast<SnWork*>(L + n);
+    SnWorkA* WA = reinterpret_cast<SnWorkA*>(W + n_work);
     long off = 0;
-    int wi = 0;
+    int wi = 0, wa = 0;
     for (int i = 0; i < n; ++i) {
         L[i].w = layers[i].w; L[i].u = layers[i].u; L[i].v = layers[i].v; L[i].sigma = layers[i].sigma;
         L[i].rows = layers[i].rows; L[i].cols = layers[i].cols;
@@ -160,20 +181,24 @@ int calm_sn_plan(const calm_sn_layer* layers, int32_t n, void* blob_host, calm_s
             W[wi].first = r0 == 0;
             ++wi;
         }
+        for (int c0 = 0; c0 < layers[i].cols; c0 += COLS_PER_WORK_A) {
+            WA[wa].layer = i; WA[wa].col0 = c0;
+            ++wa;
+        }
     }
     return 0;
 }
 
 int calm_sn_power_iter(const void* plan_dev, const calm_sn_plan_info* info, int32_t training, float eps,
                        float* scratch, void* stream) {
-    if (!plan_dev || !info || !scratch || info->n_layers <= 0 || info->n_work <= 0) return CALM_E_INVAL;
+    if (!plan_dev || !info || !scratch || info->n_layers <= 0 || info->n_work <= 0 || info->n_work_a <= 0)
+        return CALM_E_INVAL;
     hipStream_t s = as_stream(stream);
     const SnLayerDev* L = reinterpret_cast<const SnLayerDev*>(plan_dev);
     const SnWork* W = reinterpret_cast<const SnWork*>(L + info->n_layers);
     if (training) {
-        hipError_t e = hipMemsetAsync(scratch, 0, sizeof(float) * (size_t)info->scratch_floats, s);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(sn_phase_a, dim3(info->n_work), dim3(NT), 0, s, L, W, scratch);
+        const SnWorkA* WA = reinterpret_cast<const SnWorkA*>(W + info->n_work);
+        hipLaunchKernelGGL(sn_phase_a, dim3(info->n_work_a), dim3(NT), 0, s, L, WA, scratch);
         CALM_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(sn_phase_b, dim3(info->n_work), dim3(NT), 0, s, L, W, scratch, training, eps);

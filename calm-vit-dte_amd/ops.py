@@ -101,15 +101,20 @@ def _lin_wgrad(be, dy2, x2, G):
     be.gemm(dy2, x2, G, N, K, M, (1, N, 0, 0), (1, K, 0, 0), (K, 0, 0), accumulate=True)     # G comes zeroed (_zeros_big)
 
 
-# sigma.data_ptr() of the spectral-normed layers whose weight-gradient correction is applied later, by the fused
-# optimizer-side step (trainer.FusedClipAdamW registers them): their backward hands the gradient w.r.t. the
-# NORMALISED weight to autograd unchanged.
-DEFERRED_SN = set()
+# Attribute set (by trainer.FusedClipAdamW) on the weight_orig PARAMETER of a spectral-normed layer whose weight-gradient
+# correction is applied later, by the fused optimizer-side step: its backward hands the gradient w.r.t. the NORMALISED
+# weight to autograd unchanged.  The forward of every operator reads the mark from the parameter object it is given
+# (`_deferred(w)`) and keeps it in ctx for its backward.
+DEFER_ATTR = "_calm_sn_deferred"
 
 
-def _sn_wbwd(be, G, w, u, v, sigma, ls=None):
+def _deferred(w):
+    return bool(getattr(w, DEFER_ATTR, False))
+
+
+def _sn_wbwd(be, G, w, u, v, sigma, ls=None, defer=False):
     """G (grad wrt the effective weight, before LayerScale) -> (dW_orig, d_ls)."""
-    if DEFERRED_SN and sigma.data_ptr() in DEFERRED_SN:
+    if defer:
         if ls is not None:
             raise RuntimeError("a layer used with LayerScale cannot defer its spectral-norm gradient")
         return G.view_as(w), None
@@ -215,6 +220,7 @@ class SNLinearFn(Function):
         _lin_fwd(be, x2, w, sigma, out.view(-1, N), bias=bias, act=act, col_scale=ls, residual=res2,
                  pre=pre.view(-1, N) if pre is not None else None)
         ctx.act = act
+        ctx.defer = _deferred(w)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
         ctx.save_for_backward(x2, w, ls, u, v, sigma, pre)
@@ -236,7 +242,7 @@ class SNLinearFn(Function):
             dz = dy2
         G = _zeros_big(w.shape, w)
         _lin_wgrad(be, dz, x2, G)
-        dW, d_ls = _sn_wbwd(be, G, w, u, v, sigma, ls)
+        dW, d_ls = _sn_wbwd(be, G, w, u, v, sigma, ls, defer=ctx.defer)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)
@@ -275,6 +281,7 @@ class SNLinearGroupFn(Function):
         be.gemm(x2, ws, [o.view(-1, N) for o in outs], M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), batch=(n, 1),
                 inv_scale=sigmas, split_k=1)
         ctx.n = n
+        ctx.defer = [_deferred(w) for w in ws]
         ctx.xshape = x.shape
         ctx.save_for_backward(x2, *wuvs)
         return tuple(outs)
@@ -295,7 +302,7 @@ class SNLinearGroupFn(Function):
         be.gemm(dy2, x2, Gs, N, K, M, (1, N, 0, 0), (1, K, 0, 0), (K, 0, 0), batch=(n, 1), accumulate=True)
         grads = []
         for g in range(n):
-            grads += [_sn_wbwd(be, Gs[g], ws[g], us[g], vs[g], sigmas[g])[0], None, None, None]
+            grads += [_sn_wbwd(be, Gs[g], ws[g], us[g], vs[g], sigmas[g], defer=ctx.defer[g])[0], None, None, None]
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)
@@ -326,6 +333,7 @@ class MlpFn(Function):
         res2 = _c(residual).reshape(-1, N) if residual is not None else None
         _lin_fwd(be, hg, w2, s2, out.view(-1, N), bias=b2, col_scale=ls, residual=res2)
         ctx.has_b1, ctx.has_b2, ctx.has_res = b1 is not None, b2 is not None, residual is not None
+        ctx.defer = (_deferred(w1), _deferred(w2))
         ctx.xshape = x.shape
         ctx.save_for_backward(x2, hp, hg, w1, w2, ls, u1, v1, s1, u2, v2, s2)
         return out
@@ -341,7 +349,7 @@ class MlpFn(Function):
         do2 = _c(dout).reshape(-1, N)
         G2 = _zeros_big(w2.shape, w2)
         _lin_wgrad(be, do2, hg, G2)
-        dW2, d_ls = _sn_wbwd(be, G2, w2, u2, v2, s2, ls)
+        dW2, d_ls = _sn_wbwd(be, G2, w2, u2, v2, s2, ls, defer=ctx.defer[1])
         db2 = _colsum(be, do2) if ctx.has_b2 else None
         if ls is not None:
             w2l = torch.empty_like(w2)
@@ -352,7 +360,7 @@ class MlpFn(Function):
         _lin_dgrad(be, do2, w2l, s2, dhp, act=ACT_GELU_BWD, aux=hp)
         G1 = _zeros_big(w1.shape, w1)
         _lin_wgrad(be, dhp, x2, G1)
-        dW1, _ = _sn_wbwd(be, G1, w1, u1, v1, s1)
+        dW1, _ = _sn_wbwd(be, G1, w1, u1, v1, s1, defer=ctx.defer[0])
         db1 = _colsum(be, dhp) if ctx.has_b1 else None
         dx = None
         if ctx.needs_input_grad[0]:
@@ -376,6 +384,7 @@ class SeqLinearFn(Function):
         S2 = w.shape[0]
         out = torch.empty(B, S2, D, dtype=x.dtype, device=x.device)
         be.gemm(w, x, out, S2, D, S, (S, 1, 0, 0), (1, D, S * D, 0), (D, S2 * D, 0), batch=(B, 1), inv_scale=sigma)
+        ctx.defer = _deferred(w)
         ctx.save_for_backward(x, w, u, v, sigma)
         return out
 
@@ -398,7 +407,7 @@ class SeqLinearFn(Function):
         G = _zeros_big(w.shape, w)
         be.gemm(dy, x, G, S2, S, D, (D, 1, S2 * D, 0), (D, 1, S * D, 0), (S, 0, 0), batch=(B, 1), reduce_batch=True,
                 accumulate=True)
-        dW, _ = _sn_wbwd(be, G, w, u, v, sigma)
+        dW, _ = _sn_wbwd(be, G, w, u, v, sigma, defer=ctx.defer)
         return dx, dW, None, None, None
 
 
@@ -474,6 +483,7 @@ class LatentMaskAttentionFn(Function):
             be.gemm(P, v, out, Sq, hd, Skv, (Skv, 1, H * Sq * Skv, Sq * Skv), (1, D, Skv * D, hd), (D, Sq * D, hd),
                     batch=(B, H))
         ctx.H = H
+        ctx.defer = (_deferred(w1), _deferred(w2))
         ctx.save_for_backward(q, k, v, R, hp, hg, P, w1, w2, u1, v1, s1, u2, v2, s2)
         return out
 
@@ -510,14 +520,14 @@ class LatentMaskAttentionFn(Function):
         # mask MLP backward
         G2 = _zeros_big(w2.shape, w2)
         _lin_wgrad(be, dM, hg, G2)
-        dW2, _ = _sn_wbwd(be, G2, w2, u2, v2, s2)
+        dW2, _ = _sn_wbwd(be, G2, w2, u2, v2, s2, defer=ctx.defer[1])
         db2 = _colsum(be, dM)
         dhp = torch.empty_like(hp)
         _lin_dgrad(be, dM, w2, s2, dhp, act=ACT_GELU_BWD, aux=hp)
         R2 = R.view(B * Sq, Skv)
         G1 = _zeros_big(w1.shape, w1)
         _lin_wgrad(be, dhp, R2, G1)
-        dW1, _ = _sn_wbwd(be, G1, w1, u1, v1, s1)
+        dW1, _ = _sn_wbwd(be, G1, w1, u1, v1, s1, defer=ctx.defer[0])
         db1 = _colsum(be, dhp)
         dR = torch.empty(B, Sq, Skv, dtype=dt, device=dev)
         _lin_dgrad(be, dhp, w1, s1, dR.view(B * Sq, Skv))
@@ -678,6 +688,7 @@ class CnnResidualFn(Function):
         out = torch.empty_like(x)
         be.cnn_fwd(x, w0, s0, b0, w2, s2, b2, w4, s4, b4, out, B, S, Ch)
         ctx.dims = (B, S, Ch)
+        ctx.defer = (_deferred(w0), _deferred(w2), _deferred(w4))
         ctx.save_for_backward(x, w0, b0, w2, b2, w4, b4, u0, v0, s0, u2, v2, s2, u4, v4, s4)
         return out
 
@@ -694,9 +705,9 @@ class CnnResidualFn(Function):
         gall = _zeros((Ch * 3 + Ch + Ch * 9 + Ch + 3 * Ch + 3,), dy)
         G0, db0, G2, db2, G4, db4 = torch.split(gall, [Ch * 3, Ch, Ch * 9, Ch, 3 * Ch, 3])
         be.cnn_bwd(dy, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, dx, G0, db0, G2, db2, G4, db4, B, S, Ch)
-        dW0, _ = _sn_wbwd(be, G0.view(Ch, 3), w0.view(Ch, 3), u0, v0, s0)
-        dW2, _ = _sn_wbwd(be, G2.view(Ch, 9), w2.view(Ch, 9), u2, v2, s2)
-        dW4, _ = _sn_wbwd(be, G4.view(3, Ch), w4.view(3, Ch), u4, v4, s4)
+        dW0, _ = _sn_wbwd(be, G0.view(Ch, 3), w0.view(Ch, 3), u0, v0, s0, defer=ctx.defer[0])
+        dW2, _ = _sn_wbwd(be, G2.view(Ch, 9), w2.view(Ch, 9), u2, v2, s2, defer=ctx.defer[1])
+        dW4, _ = _sn_wbwd(be, G4.view(3, Ch), w4.view(3, Ch), u4, v4, s4, defer=ctx.defer[2])
         return (dx, dW0.view_as(w0), db0, dW2.view_as(w2), db2, dW4.view_as(w4), db4,
                 None, None, None, None, None, None, None, None, None)
 

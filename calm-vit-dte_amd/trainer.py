@@ -78,16 +78,34 @@ def sync_module_states(model, src=0, bucket_bytes=256 << 20):
                 off += t.numel()
 
 
+def _bucket_groups(params, bucket_bytes, tail_bytes):
+    """Parameters in gradient-arrival order -> buckets of ~bucket_bytes; the LAST bucket (the gradients that arrive
+    when backward is about to end, whose all-reduce nothing is left to overlap with) holds at most ~tail_bytes."""
+    sizes = [p.numel() * p.element_size() for p in params]
+    tail, acc = len(params), 0
+    while tail > 1 and acc + sizes[tail - 1] <= tail_bytes:
+        tail -= 1
+        acc += sizes[tail]
+    if tail == len(params):                     # the last parameter alone exceeds tail_bytes
+        tail = len(params) - 1
+    groups = _flat_groups(params[:tail], bucket_bytes) if tail > 0 else []
+    groups.append(params[tail:])
+    return groups
+
+
 class BucketedGradReducer:
     """Mean all-reduce of all gradients in large flat buckets, overlapped with backward.
 
-    Parameters are bucketed in reverse registration order (~ the order backward produces their
-    gradients).  When the last gradient of a bucket has been accumulated, the bucket is packed and its
-    all-reduce is launched on a side stream (RCCL over xGMI on the GPU; gloo on CPU in tests).
-    `finish()` (call after backward) waits for the collectives and scatters the means back into
-    `p.grad`."""
+    Parameters are bucketed in reverse registration order (~ the order backward produces their gradients): 64 MiB
+    buckets — xGMI rings are per-link bound, so few large collectives — and a small last one, because the tail of
+    backward has nothing left to hide a collective behind.  When the last gradient of a bucket has been accumulated,
+    the bucket is packed and its all-reduce is launched on a side stream (RCCL over xGMI on the GPU: ReduceOp.AVG, the
+    mean inside the collective; gloo on CPU in tests: SUM then a scale).  `finish()` (call after backward) makes the
+    compute stream wait for the collectives and re-points every `p.grad` at its slice of the reduced bucket — no copy
+    back: the optimizer-side step reads the buckets in place, and since those addresses never change its gradient
+    pointer table is uploaded once."""
 
-    def __init__(self, model, bucket_mb=64, process_group=None):
+    def __init__(self, model, bucket_mb=64, process_group=None, tail_mb=8):
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -98,8 +116,9 @@ class BucketedGradReducer:
             return
         dev = self.params[0].device
         self.on_gpu = dev.type == "cuda"
+        self.avg_in_collective = dist.get_backend(process_group) == "nccl"
         self.side = torch.cuda.Stream(device=dev) if self.on_gpu else None
-        for group in _flat_groups(list(reversed(self.params)), bucket_mb << 20):
+        for group in _bucket_groups(list(reversed(self.params)), bucket_mb << 20, tail_mb << 20):
             n = sum(p.numel() for p in group)
             flat = torch.zeros(n, dtype=group[0].dtype, device=dev)
             views, off = [], 0
@@ -121,14 +140,17 @@ class BucketedGradReducer:
 
     def _launch(self, b):
         grads = [p.grad for p in b["params"]]
+        op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
         if self.on_gpu:
+            # the side stream starts after everything enqueued so far: the gradients exist, and the previous step's
+            # optimizer-side kernels (which read this bucket in place) have been issued before them
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
                 torch._foreach_copy_(b["views"], grads)
-                work = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+                work = dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True)
         else:
             torch._foreach_copy_(b["views"], grads)
-            work = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+            work = dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True)
         self._works.append((work, b))
 
     @torch.no_grad()
@@ -146,12 +168,14 @@ class BucketedGradReducer:
             if self.on_gpu:
                 with torch.cuda.stream(self.side):
                     work.wait()                     # side stream waits for RCCL; the host does not block
-                    torch._foreach_mul_(b["views"], inv)
-                    torch._foreach_copy_([p.grad for p in b["params"]], b["views"])
+                    if not self.avg_in_collective:
+                        b["flat"].mul_(inv)
             else:
                 work.wait()
-                torch._foreach_mul_(b["views"], inv)
-                torch._foreach_copy_([p.grad for p in b["params"]], b["views"])
+                if not self.avg_in_collective:
+                    b["flat"].mul_(inv)
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v                          # the reduced gradient, in place in its bucket
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.side)
         self._works.clear()
@@ -298,12 +322,44 @@ def evaluate(model, batches):
     return correct / max(total, 1)
 
 
+def save_samples(imgs, out_dir, prefix="sample_"):
+    """CALM_ViT_V2.py:113-118: sigmoid of the generated images [B,3,H,W], one 8-bit RGB PNG per image
+    (`<out_dir>/sample_<i>.png`).  Returns the paths.  The PNG is written with zlib only (no plotting dependency)."""
+    import struct
+    import zlib
+    os.makedirs(out_dir, exist_ok=True)
+    x = torch.sigmoid(imgs.detach().float()).permute(0, 2, 3, 1)            # HWC, as the reference hands to imsave
+    u8 = (x * 255.0).round().clamp_(0, 255).to(torch.uint8).cpu().numpy()
+
+    def chunk(tag, data):
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    paths = []
+    for i, img in enumerate(u8):
+        h, w, _ = img.shape
+        raw = b"".join(b"\x00" + img[r].tobytes() for r in range(h))         # filter type 0 per scanline
+        png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0))
+               + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+        path = os.path.join(out_dir, f"{prefix}{i}.png")
+        with open(path, "wb") as f:
+            f.write(png)
+        paths.append(path)
+    return paths
+
+
 def make_optimizer(model, lr=3.1e-3, weight_decay=0.02, betas=(0.9, 0.98), capturable=False):
     """optim.AdamW(model.parameters(), lr=3.1e-3, weight_decay=0.02, betas=(0.9, 0.98)) (cls:146,158)."""
     params = [p for p in model.parameters() if p.requires_grad]
     fused = params[0].is_cuda
     return torch.optim.AdamW(params, lr=lr, weight_decay=weight_decay, betas=betas, fused=fused,
                              capturable=capturable and fused)
+
+
+def _clear_deferred(refs, attr):
+    for r in refs:
+        p = r()
+        if p is not None and hasattr(p, attr):
+            delattr(p, attr)
 
 
 class FusedClipAdamW:
@@ -323,7 +379,6 @@ class FusedClipAdamW:
         self.be = get_backend()
         self.lr, self.weight_decay, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.step_count = 0
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         sn = {}
@@ -331,30 +386,53 @@ class FusedClipAdamW:
             for m in model.modules():
                 if isinstance(m, SpectralWeight) and not getattr(m, "layer_scaled", False):
                     sn[id(m.weight_orig)] = m
-        records, self._deferred = [], []
+        records, self._deferred, self._sn_tensors = [], [], []
         for p, ea, eas in zip(self.params, self.exp_avg, self.exp_avg_sq):
             m = sn.get(id(p))
             info = None
             if m is not None:
                 info = (m.weight_u, m.weight_v, m._sigma, m.rows, m.cols)
-                self._deferred.append(m._sigma.data_ptr())
+                self._deferred.append(p)
+                self._sn_tensors.append((m, m.weight_u.data_ptr(), m.weight_v.data_ptr(), m._sigma.data_ptr()))
             records.append({"param": p.data, "exp_avg": ea, "exp_avg_sq": eas, "sn": info})
         self._plan = self.be.optim_plan(records)
-        ops.DEFERRED_SN.update(self._deferred)
-        self._ops = ops
+        # the deferral is a mark on the PARAMETER OBJECT (ops reads it in forward), not a set of raw addresses: it
+        # survives a re-materialised buffer and cannot be inherited by an unrelated tensor at a recycled address
+        for p in self._deferred:
+            setattr(p, ops.DEFER_ATTR, True)
         # an optimizer that is dropped without close() must not leave its layers deferred (their backward would hand
         # out un-corrected gradients with nobody left to correct them)
-        self._finalizer = weakref.finalize(self, ops.DEFERRED_SN.difference_update, tuple(self._deferred))
+        self._finalizer = weakref.finalize(self, _clear_deferred, [weakref.ref(p) for p in self._deferred], ops.DEFER_ATTR)
         self.stats = torch.zeros(2, dtype=torch.float32, device=self.params[0].device)   # [grad norm, found_inf]
+
+    @property
+    def step_count(self):
+        """Completed (un-skipped) optimizer steps: the counter lives on the device and does not advance when an
+        inf/NaN gradient skips the update — torch.optim.AdamW under a GradScaler.  Reading it synchronises."""
+        return int(self._plan.step_dev.item())
 
     def close(self):
         self._finalizer()
         self._deferred = []
 
+    def _check_plan(self):
+        """The plan caches raw addresses: refuse to update orphaned storage after the model was moved / re-materialised
+        (model.to(...), .float(), a replaced buffer) once the optimizer exists."""
+        import numpy as np
+        now = np.fromiter((p.data_ptr() for p in self.params), dtype=np.uint64, count=len(self.params))
+        ok = np.array_equal(now, self._plan.param_ptrs)
+        for m, pu, pv, ps in self._sn_tensors:
+            ok = ok and m.weight_u.data_ptr() == pu and m.weight_v.data_ptr() == pv and m._sigma.data_ptr() == ps
+        if not ok:
+            raise RuntimeError("FusedClipAdamW: parameters or spectral-norm buffers were moved or replaced after the "
+                               "optimizer was built (model.to / .float / load with assign=True); build the optimizer "
+                               "after the model is on its final device")
+
     @torch.no_grad()
     def step(self, grad_scale=None):
         """One optimizer-side step on the current `.grad`s; grads are released (set to None) afterwards.
         grad_scale: device scalar the loss was multiplied by (GradScaler), or None.  Returns the stats tensor."""
+        self._check_plan()
         grads = []
         for p in self.params:
             g = p.grad
@@ -363,8 +441,7 @@ class FusedClipAdamW:
             elif not g.is_contiguous():
                 g = p.grad = g.contiguous()
             grads.append(g)
-        self.step_count += 1
-        hp = (self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_norm or 0.0, self.step_count)
+        hp = (self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_norm or 0.0, 0)
         self.be.optim_step(self._plan, grads, hp, grad_scale, self.stats)
         for p in self.params:
             p.grad = None
@@ -380,7 +457,7 @@ class FusedClipAdamW:
                                 max_norm=self.max_norm)}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
+        self._plan.step_dev.fill_(int(sd["step"]))
         for dst, src in zip(self.exp_avg, sd["exp_avg"]):
             dst.copy_(src)
         for dst, src in zip(self.exp_avg_sq, sd["exp_avg_sq"]):

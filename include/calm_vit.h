@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CALM_ABI_VERSION 3
+#define CALM_ABI_VERSION 4
 
 #define CALM_E_INVAL   (-1)   /* null pointer / negative size                 */
 #define CALM_E_LAYOUT  (-2)   /* stride pattern the kernel cannot address     */
@@ -196,6 +196,8 @@ int calm_latent_bwd(const float* dz, const float* d_kl_sum, const float* mv, con
  * Vi_Tools:137-205,380-384; CALM_ViT_V2.py:50-52,62-66), batched over a table of layers.
  * training!=0: v <- normalize(W^T u); u <- normalize(W v); sigma = u.(W v)   (in place on u,v)
  * training==0: sigma = u.(W v) with the stored u,v.
+ * Every reduction has a fixed order (no atomics): u, v, sigma are bit-reproducible, hence identical on every
+ * data-parallel rank that holds the same weights (what DDP's per-forward buffer broadcast guarantees in the reference).
  * Three launches cover ALL layers of the model (the reference issues 882 mv + 883 div per forward).
  *
  * Usage: fill a host array of calm_sn_layer (device pointers inside), call calm_sn_plan() to get
@@ -215,6 +217,7 @@ typedef struct calm_sn_plan_info {
     int64_t blob_bytes;      /* size of the plan blob */
     int64_t scratch_floats;  /* size of the per-call scratch */
     int32_t n_layers, n_work;
+    int32_t n_work_a, reserved;   /* ABI v4: work items of the column-owning W^T u pass */
 } calm_sn_plan_info;
 
 /* blob_host == NULL: only fills *info.  Otherwise writes blob_bytes bytes to blob_host. */
@@ -242,7 +245,12 @@ int calm_sn_weight_bwd(const float* G, const float* w_orig, const float* u, cons
  *
  * tensors_dev: table in device memory.  Work items are chunks of calm_optim_chunk_elems() consecutive elements of one
  * tensor: chunk_tensor_dev[k] = tensor index of chunk k, tensor.chunk0 = its first chunk.
- * scratch: 6*n_tensors + 4 floats (zeroed by the call).  stats_out[2] (device): total gradient norm, found_inf.
+ * scratch: 6*n_tensors + 4 + 3*n_chunks floats.  stats_out[2] (device): total gradient norm, found_inf.
+ * Every reduction of the call has a fixed order (per-chunk partials, summed per tensor in chunk order): given equal
+ * gradients — what the all-reduce leaves on every rank — all ranks apply bit-identical updates.
+ * step_dev (nullable, device int32, ABI v4): the bias-correction step count kept on the device; it advances by one
+ * per call EXCEPT when the update is skipped for inf/NaN gradients (torch's fused AdamW under a GradScaler), and then
+ * replaces hparams->step.
  * ------------------------------------------------------------------------------------- */
 typedef struct calm_optim_tensor {
     float*       param;
@@ -265,7 +273,8 @@ typedef struct calm_optim_hparams {
 int32_t calm_optim_chunk_elems(void);
 int calm_optim_step(const calm_optim_tensor* tensors_dev, int32_t n_tensors, const int32_t* chunk_tensor_dev,
                     int32_t n_chunks, float* scratch, const calm_optim_hparams* hparams,
-                    const float* grad_scale /* device scalar or NULL */, float* stats_out, void* stream);
+                    const float* grad_scale /* device scalar or NULL */, float* stats_out, int32_t* step_dev,
+                    void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Device-side batch collate feeding the path: uint8 images [B,3,H,W] -> normalised fp32 batch with

@@ -127,11 +127,18 @@ class EmulatedBackend:
         out.copy_(x)
 
     def optim_plan(self, records):
-        return records
+        import numpy as np
+        plan = EmuPlan([])
+        plan.records = records
+        plan.step_dev = torch.zeros(1, dtype=torch.int32)
+        plan.param_ptrs = np.asarray([r["param"].data_ptr() for r in records], dtype=np.uint64)
+        return plan
 
     def optim_step(self, plan, grads, hp, grad_scale, stats_out):
-        """calm_optim_step: deferred spectral-norm correction, global norm, clip, torch.optim.AdamW's update."""
-        lr, b1, b2, eps, wd, max_norm, step = hp
+        """calm_optim_step: deferred spectral-norm correction, global norm, clip, torch.optim.AdamW's update; the step
+        count lives in plan.step_dev and does not advance on a skipped (inf/NaN) step."""
+        lr, b1, b2, eps, wd, max_norm, _ = hp
+        plan, step_dev = plan.records, plan.step_dev
         fixed = []
         for r, g in zip(plan, grads):
             if r["sn"] is not None:
@@ -146,6 +153,8 @@ class EmulatedBackend:
         stats_out[0], stats_out[1] = norm, float(bad)
         if bad:
             return
+        step_dev += 1
+        step = int(step_dev)
         mul = (min(1.0, max_norm / (float(norm) + 1e-6)) if max_norm > 0 else 1.0) * inv
         bc1, bc2 = 1 - b1 ** step, 1 - b2 ** step
         for r, g in zip(plan, fixed):

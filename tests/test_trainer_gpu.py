@@ -163,7 +163,7 @@ def test_fused_optimizer_side_step_matches_clip_plus_adamw(name):
     start = {k: v.clone() for k, v in m0.state_dict().items()}
     m_ref, _ = _one_step(name, fused=False, steps=1)
     m_fus, norms = _one_step(name, fused=True, steps=1)
-    assert not calm.ops.DEFERRED_SN                       # close() restored the in-backward correction
+    assert not any(hasattr(p, calm.ops.DEFER_ATTR) for p in m_fus.parameters())   # close() restored the in-backward correction
     assert all(n > 0 and n == n for n in norms)
     sd_r, sd_f = m_ref.state_dict(), m_fus.state_dict()
     bad = tot = 0
@@ -204,8 +204,10 @@ def test_fused_optimizer_gradient_norm_and_skip_on_nonfinite():
         y_hat, _ = m(x.cuda())
         trainer.soft_target_cross_entropy(y_hat.squeeze(), y.cuda()).backward()
         next(iter(m.parameters())).grad[0] = float("inf")
+        assert opt.step_count == 1
         opt.step()
         assert float(opt.stats[1]) == 1.0
+        assert opt.step_count == 1                     # a skipped step does not advance the bias-correction count
         for k, v in m.state_dict().items():
             if k in snap:
                 assert torch.equal(v, snap[k]), k
@@ -267,12 +269,9 @@ def test_bench_two_rank_path_rehearsed_on_one_gpu():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, CALM_DIST_BACKEND="gloo", CALM_LOCAL_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "nano48",
+    # no external launcher: `python bench.py --gpus 2` starts its own two ranks (bench.self_launch)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "nano48",
            "--batch", "8", "--steps", "2", "--warmup", "1", "--prof-steps", "1"]
     out = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=500)
     assert out.returncode == 0, out.stderr[-2000:]
@@ -280,3 +279,144 @@ def test_bench_two_rank_path_rehearsed_on_one_gpu():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 16 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["roofline"]["bound"] == "mfma" and "cpu_baseline" not in d
+    assert d["config"]["world"] == 2 and d["config"]["backend"] == "gloo"
+
+
+def test_fused_optimizer_step_is_safe_when_the_host_runs_ahead_of_the_gpu():
+    """The gradient-pointer table of calm_optim_step travels through pinned staging memory; the host enqueues steps
+    faster than a large batch executes, so without per-slot events a later step's pointers would overwrite the staging
+    buffer before the copy of an earlier step has run.  Four steps without any host synchronisation must leave the same
+    parameters as four steps synchronised one by one."""
+    name = "tiny32_cls"
+    g = load_golden(name)
+    cfg, x, y = _batch(name, bs=2048)                  # ~tens of ms of GPU work per step: the host gets ahead
+    x, y = x.cuda(), y.cuda()
+    outs = []
+    for synced in (True, False):
+        m = build_model(name, g, "cuda").train()
+        opt = trainer.FusedClipAdamW(m)
+        step = trainer.TrainStep(m, opt, None)
+        try:
+            for _ in range(4):
+                step(x, y)
+                if synced:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            assert opt.step_count == 4 and float(opt.stats[1]) == 0.0
+        finally:
+            opt.close()
+        outs.append({k: v.clone() for k, v in m.state_dict().items()})
+    start = build_model(name, g, "cuda").state_dict()
+    bad = tot = 0
+    for k in outs[0]:
+        if O.is_buffer(k):
+            continue
+        d0, d1 = outs[0][k] - start[k], outs[1][k] - start[k]
+        bad += int(((d1 - d0).abs() > 2e-3 * 4 * 3.1e-3 + 1e-7).sum())
+        tot += d0.numel()
+    assert bad <= 1e-3 * tot, (bad, tot)
+
+
+def test_optimizer_side_step_and_power_iteration_are_bit_reproducible():
+    """Data-parallel replicas stay identical only if everything computed AFTER the gradient all-reduce is a pure
+    function of its inputs: the spectral-norm power iteration (u, v, sigma) and calm_optim_step (norm, clip
+    coefficient, spectral-norm correction, AdamW) use fixed-order reductions — the same gradients twice give the same
+    bits."""
+    name = "nano48_cls"
+    g = load_golden(name)
+    cfg, x, y = _batch(name, bs=4)
+    m = build_model(name, g, "cuda").train()
+    calm.ops.set_noise_override(W.NoiseStream(3))
+    try:
+        y_hat, _ = m(x.cuda())
+        trainer.soft_target_cross_entropy(y_hat.squeeze(), y.cuda()).backward()
+    finally:
+        calm.ops.set_noise_override(None)
+    grads = [p.grad.clone() for p in m.parameters()]
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    results = []
+    for _ in range(2):
+        m2 = build_model(name, g, "cuda").train()
+        m2.load_state_dict(state)
+        opt = trainer.FusedClipAdamW(m2)
+        try:
+            for p, gr in zip(m2.parameters(), grads):
+                p.grad = gr.clone()
+            opt.step()
+            with torch.no_grad():                         # next forward: power iteration on the updated weights
+                calm.ops.set_noise_override(W.NoiseStream(4))
+                m2(x.cuda())
+                calm.ops.set_noise_override(None)
+        finally:
+            opt.close()
+        results.append(({k: v.clone() for k, v in m2.state_dict().items()}, opt.stats.clone()))
+    (sd_a, st_a), (sd_b, st_b) = results
+    assert torch.equal(st_a, st_b)
+    for k in sd_a:
+        assert torch.equal(sd_a[k], sd_b[k]), k
+
+
+def test_generative_trainer_step_matches_oracle_iteration():
+    """trainer.RegTrainStep on the HIP path (distributed_trainer_reg.py:71-95: tokens -> image view, Huber(img, x) +
+    0.1 * kl, scale / clip(1.0) / optimizer step) against the same iteration driven through the CPU oracle."""
+    name = "nano48_gen"
+    g = load_golden(name)
+    cfg = CONFIGS[name]
+    x = torch.from_numpy(W.make_input((2, 3, cfg.seq_length, cfg.seq_length), 2))
+    P = {k: torch.from_numpy(v) for k, v in W.make_params(O.vit_param_shapes(cfg), 1234).items()}
+    for k in P:
+        if O.is_buffer(k):
+            P[k] = torch.from_numpy(g["warm/" + k].copy())
+    leaves = {k: P[k].requires_grad_(True) for k in P if not O.is_buffer(k)}
+    before = {k: v.detach().clone() for k, v in leaves.items()}
+    opt_o = torch.optim.AdamW(list(leaves.values()), lr=3.1e-3, weight_decay=0.02, betas=(0.9, 0.98))
+    y_o, kl_o = O.vit_forward(P, cfg, x, True, W.NoiseStream(7))
+    img_o = y_o.reshape(-1, cfg.seq_length, cfg.seq_length, 3).permute(0, 3, 1, 2)
+    loss_o = torch.nn.functional.huber_loss(img_o, x) + 0.1 * kl_o
+    loss_o.backward()
+    norm_o = torch.nn.utils.clip_grad_norm_(list(leaves.values()), 1.0)
+    grads_o = {k: v.grad.clone() for k, v in leaves.items()}
+    opt_o.step()
+    m = build_model(name, g, "cuda").train()
+    opt = trainer.FusedClipAdamW(m)
+    step = trainer.RegTrainStep(m, opt, None)
+    calm.ops.set_noise_override(W.NoiseStream(7))
+    try:
+        loss_h, img_h = step(x.cuda())
+    finally:
+        calm.ops.set_noise_override(None)
+        opt.close()
+    assert img_h.shape == x.shape
+    assert rel_err(img_h, img_o.detach()) < 1e-3
+    assert abs(float(loss_h) - float(loss_o)) < 1e-4 * max(1.0, abs(float(loss_o)))
+    assert abs(float(opt.stats[0]) - float(norm_o)) < 1e-3 * float(norm_o)
+    bad = tot = 0
+    for k, p in m.named_parameters():
+        sel = grads_o[k].abs() > 1e-6 * grads_o[k].abs().max()
+        d_h = (p.detach().cpu() - before[k])[sel]
+        d_o = (leaves[k].detach() - before[k])[sel]
+        bad += int(((d_h - d_o).abs() > 1e-3 * 3.1e-3 + 1e-7).sum())
+        tot += int(sel.sum())
+    assert bad <= 2e-3 * tot, (bad, tot)
+
+
+def test_eval_loop_top1_accuracy(tmp_path):
+    """trainer.evaluate (CALM_ViT_V2.py:228-239) on the HIP path: eval mode, argmax over the logits, accuracy over
+    batches; and save_samples (CALM_ViT_V2.py:113-118) writes one PNG per generated image."""
+    mc = build_model("nano48_cls", load_golden("nano48_cls"), "cuda")
+    xs = torch.from_numpy(W.make_input((4, 3, 48, 48), 5)).cuda()
+    with torch.no_grad():
+        labels = mc.eval()(xs)[0].reshape(4, -1).argmax(dim=1)
+    mc.train()
+    assert trainer.evaluate(mc, [(xs[:2], labels[:2]), (xs[2:], labels[2:])]) == 1.0
+    assert trainer.evaluate(mc, [(xs, (labels + 1) % 10)]) == 0.0
+    assert mc.training                                   # the loop restores the mode it found
+    mg = build_model("nano48_gen", load_golden("nano48_gen"), "cuda").eval()
+    with torch.no_grad():
+        tok, _ = mg(xs[:2])
+    imgs = tok.reshape(-1, 48, 48, 3).permute(0, 3, 1, 2)
+    paths = trainer.save_samples(imgs, str(tmp_path))
+    assert len(paths) == 2
+    for pth in paths:
+        with open(pth, "rb") as f:
+            assert f.read(8) == b"\x89PNG\r\n\x1a\n"
