@@ -10,7 +10,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcalmvit_hip.so")
-SOURCES = ["gemm.hip", "norm_act.hip", "spectral.hip", "tokens_conv.hip", "cnn_fused.hip", "attention_fused.hip", "optim.hip"]
+SOURCES = ["gemm.hip", "gemm_f32.hip", "gemm_bf16.hip", "norm_act.hip", "spectral.hip", "tokens_conv.hip", "cnn_fused.hip",
+           "attention_fused.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -31,10 +32,11 @@ def _stale(target, deps):
 def build_library(force=False, verbose=False):
     """Build (if stale) and return the path of libcalmvit_hip.so."""
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "calm_vit.h")]
+    headers = [os.path.join(CSRC, h) for h in os.listdir(CSRC) if h.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "calm_vit.h"))
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    objs = []
+    objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(objdir, src.replace(".hip", ".o"))
@@ -42,8 +44,11 @@ def build_library(force=False, verbose=False):
             cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
-            subprocess.run(cmd, check=True)
+            jobs.append((src, subprocess.Popen(cmd)))          # one compiler process per stale translation unit
         objs.append(o)
+    failed = [src for src, pr in jobs if pr.wait() != 0]
+    if failed:
+        raise RuntimeError(f"hipcc failed for {failed}")
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

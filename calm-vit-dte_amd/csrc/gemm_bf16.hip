@@ -1,0 +1,436 @@
+// bf16-operand kernel family of calm_gemm (dispatcher: gemm.hip; shared pieces: gemm_common.h).
+#include "gemm_common.h"
+
+namespace calm_gemm_detail {
+
+// =====================================================================================================
+// bf16-operand GEMM family: tensors stay fp32 in HBM; operands are converted to bf16 while being staged
+// into LDS and multiplied on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate) with fp32 accumulation.
+//   NPASS == 1: plain bf16 operands                  (what autocast(bfloat16) computes for Linear/matmul)
+//   NPASS == 3: split a = hi + lo (both bf16); acc += hi*hi + hi*lo + lo*hi   ("bf16x3": products accurate to
+//               ~2^-17 relative, i.e. fp32-level results at a fraction of the fp32-MFMA time, because the
+//               kernel is bound by staging fp32 bytes, not by the matrix pipe).
+// k-contiguous operands use a [row][k] LDS image (80-byte rows: conflict-free ds_read_b128 fragments);
+// row-contiguous ("transposed") operands keep their natural [k][row] image (320-byte rows), written with
+// contiguous ds_write_b64 and read as k-contiguous MFMA fragments by ds_read_b64_tr_b16.
+// =====================================================================================================
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int KC_LD = 40;              // bf16 per row of a [row][k] image
+constexpr int MC_LD = 160;             // bf16 per k-row of a [k][row] image
+constexpr int PLANE = 128 * KC_LD;     // == 32 * MC_LD bf16 = 10240 B
+
+template <bool KC, int ROWS>
+__device__ __forceinline__ void c_load(const float* __restrict__ base, long rs, long cs, int row0, int nrows_all,
+                                       int k0, int K, f32x4 (&reg)[4]) {
+    const int tid = threadIdx.x;
+    const int nrows = min(nrows_all, row0 + ROWS);
+    if constexpr (KC) {
+        const int k = k0 + 4 * (tid & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = row0 + (tid >> 3) + 32 * i;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < nrows && k < K) v = *reinterpret_cast<const f32x4*>(base + (long)row * rs + k);
+            reg[i] = v;
+        }
+    } else {
+        const int row = row0 + 4 * (tid & 31);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + 4 * (tid >> 5) + j;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < nrows && k < K) v = *reinterpret_cast<const f32x4*>(base + (long)k * cs + row);
+            reg[j] = v;
+        }
+    }
+}
+
+// cursor form of c_load (see OperandCursor): row addresses once per (tile, batch entry), clamped edge rows,
+// unconditional 16-byte loads for full k-blocks
+template <bool KC, int ROWS>
+struct CCursor {
+    const float* base;
+    unsigned off[4];
+    long step;
+    __device__ __forceinline__ void init(const float* origin, long rs, long cs, int row0, int nrows_all, int k0) {
+        const int tid = threadIdx.x;
+        const int last = min(nrows_all - row0, ROWS) - 1;
+        if constexpr (KC) {
+            base = origin + (long)row0 * rs + k0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) off[i] = (unsigned)(min((tid >> 3) + 32 * i, last) * rs + 4 * (tid & 7)) * 4u;
+            step = CK;
+        } else {
+            base = origin + (long)k0 * cs + row0;
+            const int row = min(4 * (tid & 31), last & ~3);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) off[j] = (unsigned)((4 * (tid >> 5) + j) * cs + row) * 4u;
+            step = CK * cs;
+        }
+    }
+    template <bool FULL>
+    __device__ __forceinline__ void load(int k_left, f32x4 (&reg)[4]) {
+        const int tid = threadIdx.x;
+        const char* b = reinterpret_cast<const char*>(base);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f32x4 v;
+            if constexpr (FULL) {
+                v = *reinterpret_cast<const f32x4*>(b + off[i]);
+            } else {
+                const int k = KC ? 4 * (tid & 7) : 4 * (tid >> 5) + i;
+                v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (k < k_left) v = *reinterpret_cast<const f32x4*>(b + off[i]);
+            }
+            reg[i] = v;
+        }
+        base += step;
+    }
+};
+
+template <int NPASS>
+__device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hi[e] = (__bf16)v[e];
+        if constexpr (NPASS == 3) lo[e] = (__bf16)(v[e] - (float)hi[e]);
+    }
+}
+
+template <bool KC, int NPASS>
+__device__ __forceinline__ void c_store(__bf16* __restrict__ hi_plane, __bf16* __restrict__ lo_plane,
+                                        const f32x4 (&reg)[4]) {
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        bf16x4 hi, lo;
+        split4<NPASS>(reg[i], hi, lo);
+        int off;
+        if constexpr (KC) off = ((tid >> 3) + 32 * i) * KC_LD + 4 * (tid & 7);          // [row][k]
+        else off = (4 * (tid >> 5) + i) * MC_LD + 4 * (tid & 31);                       // [k][row]
+        *reinterpret_cast<bf16x4*>(hi_plane + off) = hi;
+        if constexpr (NPASS == 3) *reinterpret_cast<bf16x4*>(lo_plane + off) = lo;
+    }
+}
+
+// MFMA A/B fragment (8 consecutive k for row `rowbase + (lane&31)`, k = 16*s + 8*(lane>>5) + 0..7)
+template <bool KC, int LD = MC_LD>
+__device__ __forceinline__ bf16x8 c_frag(const __bf16* __restrict__ plane, int rowbase, int s, int lane) {
+    if constexpr (KC) {
+        return *reinterpret_cast<const bf16x8*>(plane + (rowbase + (lane & 31)) * KC_LD + 16 * s + 8 * (lane >> 5));
+    } else {
+        // hardware transpose read: each 16-lane group fetches a 4(k) x 16(row) block and gets it column-major
+        const int q = (lane & 15) >> 2, pp = lane & 3, gi = lane >> 4;
+        const __bf16* a0 = plane + (16 * s + 8 * (gi >> 1) + q) * LD + rowbase + 16 * (gi & 1) + 4 * pp;
+        const s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(a0));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(a0 + 4 * LD));
+        s16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+}
+
+template <bool AKC, bool BKC, int NPASS, int BN_>
+__global__ __launch_bounds__(NTHREADS, NPASS == 3 ? 2 : CALM_GEMM_BF16_WAVES) void gemm_bf16c_kernel(const GemmP p) {
+    constexpr int WN = BN_ == 128 ? 2 : 1;
+    constexpr int MT = BN_ == 128 ? 2 : 1;
+    constexpr int NT = BN_ / (WN * 32);
+    constexpr int NPL = NPASS == 3 ? 2 : 1;                     // planes per operand (hi [, lo])
+    __shared__ __attribute__((aligned(16))) __bf16 lds[2][2][NPL][PLANE];   // [stage][A|B][plane]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int tiles = p.tiles_m * p.tiles_n;
+    int lin = blockIdx.x;
+    if (tiles >= 8) {
+        const int q = tiles >> 3, rem = tiles & 7, x = lin & 7, idx = lin >> 3;
+        lin = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + idx;
+    }
+    const int tn = lin % p.tiles_n, tm = lin / p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN_;
+    // grid.y: batch entry (plain), k-slice of the concatenated reduction (split-K / reduce_batch), or — batched
+    // split-K, slices_per_batch > 0 — k-slice `z % spb` of batch entry `z / spb` (entry-local reduction range)
+    int z = blockIdx.y;
+    int kb_begin = z * p.kb_per_z;
+    int kb_end = min(kb_begin + p.kb_per_z, p.kb_total);
+    if (p.slices_per_batch) {
+        const int b = z / p.slices_per_batch, sl = z - b * p.slices_per_batch;
+        kb_begin = b * p.kpb + sl * p.kb_per_z;
+        kb_end = min(kb_begin + p.kb_per_z, (b + 1) * p.kpb);
+        z = b;                                   // the epilogue's batch index
+    }
+    if (kb_begin >= kb_end && p.atomic) return;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 ra[4], rb[4];
+    CCursor<AKC, BM> ca;
+    CCursor<BKC, BN_> cb;
+    // one copy of the k-loop per case (whole k-tiles / tailed K): see OperandCursor::load
+    auto k_loop = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    int cur_b = -1;
+    auto fetch = [&](int kb) {
+        const int b = p.kb_total == p.kpb ? 0 : kb / p.kpb;
+        const int k0 = (kb - b * p.kpb) * CK;
+        if (b != cur_b) {
+            const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
+            ca.init(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, k0);
+            cb.init(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
+            cur_b = b;
+        }
+        ca.template load<FULL>(p.K - k0, ra);
+        cb.template load<FULL>(p.K - k0, rb);
+    };
+    auto stash = [&](int st) {
+        c_store<AKC, NPASS>(lds[st][0][0], lds[st][0][NPL - 1], ra);
+        c_store<BKC, NPASS>(lds[st][1][0], lds[st][1][NPL - 1], rb);
+    };
+
+    int buf = 0;
+    if (kb_begin < kb_end) {
+        fetch(kb_begin);
+        stash(0);
+    }
+    __syncthreads();
+
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+        const bool more = kb + 1 < kb_end;
+        if (p.reduce_group && kb != kb_begin && kb % p.kpb == 0) group_rescale<MT, NT>(p, acc, kb / p.kpb);
+        if (more) fetch(kb + 1);
+#pragma unroll
+        for (int s = 0; s < CK / 16; ++s) {
+            bf16x8 ah[MT], bh[NT], al[MT], bl[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                ah[i] = c_frag<AKC>(lds[buf][0][0], wm * (32 * MT) + 32 * i, s, lane);
+                if constexpr (NPASS == 3) al[i] = c_frag<AKC>(lds[buf][0][NPL - 1], wm * (32 * MT) + 32 * i, s, lane);
+            }
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                bh[j] = c_frag<BKC>(lds[buf][1][0], wn * (32 * NT) + 32 * j, s, lane);
+                if constexpr (NPASS == 3) bl[j] = c_frag<BKC>(lds[buf][1][NPL - 1], wn * (32 * NT) + 32 * j, s, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if constexpr (NPASS == 3) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) stash(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+    };
+    if (p.K % CK == 0) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
+    gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
+}
+
+// ---- wide tile of the bf16-operand family: 256x128x32 per 512-thread workgroup (8 waves as 4x2, each 64x64) ----
+// The 128-row tiles above are bound by re-reading the fp32 operand panels from L2 / Infinity Cache (32 flop per
+// byte staged); 256 rows raise that to 42.7.  60 KB LDS, <=128 VGPRs: two workgroups (16 waves) per CU.  Used for
+// the data-parallel launches (forward, data gradients) with enough tiles to fill the chip; NPASS == 1 only.
+constexpr int MC_LDW = 288;                  // bf16 per k-row of a 256-row [k][row] image (same bank residue as 160)
+constexpr int WPLANE_A = WBM * KC_LD;        // 20480 B (>= 32 * MC_LDW)
+
+template <bool KC, int ROWS>
+struct WCursor {
+    static constexpr int NV = ROWS * CK / (4 * WTHREADS);     // 16-byte vectors per thread per k-tile (4 or 2)
+    static constexpr int LD = ROWS == WBM ? MC_LDW : MC_LD;
+    const float* base;
+    unsigned off[NV];
+    long step;
+    __device__ __forceinline__ void init(const float* origin, long rs, long cs, int row0, int nrows_all, int k0) {
+        const int tid = threadIdx.x;
+        const int last = min(nrows_all - row0, ROWS) - 1;
+        if constexpr (KC) {
+            base = origin + (long)row0 * rs + k0;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) off[i] = (unsigned)(min((tid >> 3) + 64 * i, last) * rs + 4 * (tid & 7)) * 4u;
+            step = CK;
+        } else {
+            constexpr int LPR = ROWS / 4;                     // threads across the rows
+            base = origin + (long)k0 * cs + row0;
+            const int row = min(4 * (tid % LPR), last & ~3);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) off[j] = (unsigned)((NV * (tid / LPR) + j) * cs + row) * 4u;
+            step = CK * cs;
+        }
+    }
+    template <bool FULL>
+    __device__ __forceinline__ void load(int k_left, f32x4 (&reg)[NV]) {
+        const int tid = threadIdx.x;
+        const char* b = reinterpret_cast<const char*>(base);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            f32x4 v;
+            if constexpr (FULL) {
+                v = *reinterpret_cast<const f32x4*>(b + off[i]);
+            } else {
+                const int k = KC ? 4 * (tid & 7) : NV * (tid / (ROWS / 4)) + i;
+                v = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (k < k_left) v = *reinterpret_cast<const f32x4*>(b + off[i]);
+            }
+            reg[i] = v;
+        }
+        base += step;
+    }
+    __device__ __forceinline__ void store(__bf16* __restrict__ plane, const f32x4 (&reg)[NV]) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            bf16x4 hi, lo;
+            split4<1>(reg[i], hi, lo);
+            int off;
+            if constexpr (KC) off = ((tid >> 3) + 64 * i) * KC_LD + 4 * (tid & 7);
+            else off = (NV * (tid / (ROWS / 4)) + i) * LD + 4 * (tid % (ROWS / 4));
+            *reinterpret_cast<bf16x4*>(plane + off) = hi;
+        }
+    }
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) {
+    constexpr int MT = 2, NT = 2;
+    __shared__ __attribute__((aligned(16))) __bf16 lds_a[2][WPLANE_A];
+    __shared__ __attribute__((aligned(16))) __bf16 lds_b[2][PLANE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r = lane & 31, h = lane >> 5;
+
+    const int tiles = p.tiles_m * p.tiles_n;
+    int lin = blockIdx.x;
+    if (tiles >= 8) {
+        const int q = tiles >> 3, rem = tiles & 7, x = lin & 7, idx = lin >> 3;
+        lin = (x < rem ? x * (q + 1) : rem * (q + 1) + (x - rem) * q) + idx;
+    }
+    const int tn = lin % p.tiles_n, tm = lin / p.tiles_n;
+    const int m0 = tm * WBM, n0 = tn * WBN;
+    int z = blockIdx.y;
+    int kb_begin = z * p.kb_per_z;
+    int kb_end = min(kb_begin + p.kb_per_z, p.kb_total);
+    if (p.slices_per_batch) {                        // batched split-K (grouped weight gradients), as in the 128-row kernels
+        const int b = z / p.slices_per_batch, sl = z - b * p.slices_per_batch;
+        kb_begin = b * p.kpb + sl * p.kb_per_z;
+        kb_end = min(kb_begin + p.kb_per_z, (b + 1) * p.kpb);
+        z = b;
+    }
+    if (kb_begin >= kb_end && p.atomic) return;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    WCursor<AKC, WBM> ca;
+    WCursor<BKC, WBN> cb;
+    f32x4 ra[WCursor<AKC, WBM>::NV], rb[WCursor<BKC, WBN>::NV];
+    auto k_loop = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    int cur_b = -1;
+    auto fetch = [&](int kb) {
+        const int b = p.kb_total == p.kpb ? 0 : kb / p.kpb;
+        const int k0 = (kb - b * p.kpb) * CK;
+        if (b != cur_b) {
+            const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
+            ca.init(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, k0);
+            cb.init(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
+            cur_b = b;
+        }
+        ca.template load<FULL>(p.K - k0, ra);
+        cb.template load<FULL>(p.K - k0, rb);
+    };
+
+    int buf = 0;
+    if (kb_begin < kb_end) {
+        fetch(kb_begin);
+        ca.store(lds_a[0], ra);
+        cb.store(lds_b[0], rb);
+    }
+    __syncthreads();
+
+    for (int kb = kb_begin; kb < kb_end; ++kb) {
+        const bool more = kb + 1 < kb_end;
+        if (p.reduce_group && kb != kb_begin && kb % p.kpb == 0) group_rescale<MT, NT>(p, acc, kb / p.kpb);
+        if (more) fetch(kb + 1);
+#pragma unroll
+        for (int s = 0; s < CK / 16; ++s) {
+            bf16x8 af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = c_frag<AKC, MC_LDW>(lds_a[buf], wm * 64 + 32 * i, s, lane);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = c_frag<BKC, MC_LD>(lds_b[buf], wn * 64 + 32 * j, s, lane);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            ca.store(lds_a[buf ^ 1], ra);
+            cb.store(lds_b[buf ^ 1], rb);
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    };
+    if (p.K % CK == 0) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
+    gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
+}
+
+int launch_wide(const GemmP& p, dim3 grid, bool akc, bool bkc, hipStream_t s) {
+    if (akc && bkc) hipLaunchKernelGGL((gemm_bf16w_kernel<true, true>), grid, dim3(WTHREADS), 0, s, p);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16w_kernel<true, false>), grid, dim3(WTHREADS), 0, s, p);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf16w_kernel<false, true>), grid, dim3(WTHREADS), 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16w_kernel<false, false>), grid, dim3(WTHREADS), 0, s, p);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+template <bool AKC, bool BKC, int NPASS>
+int launch_c(const GemmP& p, dim3 grid, int bn, hipStream_t s) {
+    if (bn == 128) hipLaunchKernelGGL((gemm_bf16c_kernel<AKC, BKC, NPASS, 128>), grid, dim3(NTHREADS), 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16c_kernel<AKC, BKC, NPASS, 96>), grid, dim3(NTHREADS), 0, s, p);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int NPASS>
+int launch_c_layout(const GemmP& p, dim3 grid, int bn, bool akc, bool bkc, hipStream_t s) {
+    if (akc && bkc) return launch_c<true, true, NPASS>(p, grid, bn, s);
+    if (akc && !bkc) return launch_c<true, false, NPASS>(p, grid, bn, s);
+    if (!akc && bkc) return launch_c<false, true, NPASS>(p, grid, bn, s);
+    return launch_c<false, false, NPASS>(p, grid, bn, s);
+}
+
+int launch_bf16(const GemmP& p, dim3 grid, int bn, bool akc, bool bkc, int npass, hipStream_t s) {
+    if (npass == 3) return launch_c_layout<3>(p, grid, bn, akc, bkc, s);
+    return launch_c_layout<1>(p, grid, bn, akc, bkc, s);
+}
+int launch_bf16_wide(const GemmP& p, dim3 grid, bool akc, bool bkc, hipStream_t s) { return launch_wide(p, grid, akc, bkc, s); }
+
+}  // namespace calm_gemm_detail

@@ -7,8 +7,11 @@ from the imported reference at batch 1 (tests/golden/make_golden.py: golden_<cfg
       - against the fp32 reference fixture within BF16_VS_FP32 (stated below; bf16 has 8 significant bits and the
         logits pass through 24 blocks), and
       - against an emulation of exactly the library's rounding points (the package's host logic over
-        tests/emulated_backend.py on CPU, same inputs and noise) within BF16_VS_EMULATION — only the fp32 accumulation
-        order differs there.
+        tests/emulated_backend.py on CPU, same inputs and noise): only the fp32 accumulation order differs, but a
+        1e-6 difference in a GEMM input flips its bf16 rounding now and then (one flip moves an output by
+        ~2^-8/sqrt(K)), and the network amplifies such perturbations block after block.  Measured on MI355X:
+        one block 2e-4 (output) / 7e-4 (input gradient) — BF16_VS_EMULATION_BLOCK is the tight bound — growing to
+        3e-3 ... 1.1e-2 behind 24 blocks, where it is bounded by BF16_VS_EMULATION_MODEL.
 """
 import pytest
 import torch
@@ -24,7 +27,9 @@ from test_host_logic_cpu import build_model
 pytestmark = pytest.mark.gpu
 TOL = 1e-3                    # north_star: 1e-3 rel fp32
 BF16_VS_FP32 = 4e-2           # bf16-operand matmuls against the fp32 reference (logits / dL/dx, max-abs relative)
-BF16_VS_EMULATION = 1e-2      # ... against the emulation of the same rounding points (accumulation order only)
+BF16_VS_EMULATION_BLOCK = 1e-3  # one block against the emulation of the same rounding points: output (x3 for gradients)
+BF16_VS_EMULATION = 2.5e-2    # = BF16_VS_EMULATION_MODEL: the full model (24 blocks) against that emulation
+BF16_GRAD_EACH = 6e-2         # ... each single parameter's gradient norm against the emulation
 
 
 @pytest.fixture(autouse=True)
@@ -97,13 +102,21 @@ def test_full_model_bf16_vs_fp32_fixture_and_vs_rounding_emulation(name):
     assert rel_err(y, ye) < BF16_VS_EMULATION
     assert abs(float(kl) - float(kle)) < BF16_VS_EMULATION * max(1.0, abs(float(kle)))
     assert rel_err(x.grad, xe.grad) < BF16_VS_EMULATION
+    # gradients: the global norm tightly; each parameter's own norm within BF16_GRAD_EACH (a bias gradient is a sum
+    # with heavy cancellation: the order of the fp32 accumulation — atomics on the GPU — moves it more than a matrix)
     pe = dict(me.named_parameters())
+    tot_h = sum(float(p.grad.double().pow(2).sum()) for p in m.parameters()) ** 0.5
+    tot_e = sum(float(p.grad.double().pow(2).sum()) for p in me.parameters()) ** 0.5
     worst = max((abs(float(p.grad.norm()) - float(pe[n].grad.norm())) / max(float(pe[n].grad.norm()), 1e-6), n)
                 for n, p in m.named_parameters())
-    assert worst[0] < BF16_VS_EMULATION, worst
+    print(f"\n[{name}] bf16 vs fp32 fixture: y {rel_err(y, g['train/y']):.2e} dx {rel_err(x.grad, g['train/dx']):.2e}; "
+          f"vs emulation: y {rel_err(y, ye):.2e} dx {rel_err(x.grad, xe.grad):.2e} |grad| {abs(tot_h - tot_e) / tot_e:.2e} "
+          f"worst param {worst[0]:.2e} {worst[1]}")
+    assert abs(tot_h - tot_e) < 1e-3 * tot_e
+    assert worst[0] < BF16_GRAD_EACH, worst
 
 
-def _block_on_gpu(name, precision):
+def _block_on_gpu(name, precision, device="cuda"):
     vt = calm.Vi_Tools_CNN_less_V2
     g = load_golden("block_" + name)
     kw = BLOCK_FIXTURES[name]
@@ -111,16 +124,16 @@ def _block_on_gpu(name, precision):
     blk = vt.VMLA_Block(mlp_dim=2 * kw["dim2"], force_reduce=False, **kw)
     assert {k: tuple(v.shape) for k, v in blk.state_dict().items()} == shapes
     blk.load_state_dict({k: v.clone() for k, v in P.items()})
-    blk = blk.cuda().train()
+    blk = blk.to(device).train()
     S, D1 = kw["seq_length"], kw["dim1"]
-    xq = torch.from_numpy(W.make_input((1, S, D1), 5, "xq")).cuda().requires_grad_(True)
-    xkv = torch.from_numpy(W.make_input((1, S, D1), 6, "xkv")).cuda().requires_grad_(True) if kw["is_cross"] else None
+    xq = torch.from_numpy(W.make_input((1, S, D1), 5, "xq")).to(device).requires_grad_(True)
+    xkv = torch.from_numpy(W.make_input((1, S, D1), 6, "xkv")).to(device).requires_grad_(True) if kw["is_cross"] else None
     sm = vt.ResidualStateManager(mode="sum")
     calm.backend.set_matmul_precision(precision)
     calm.ops.set_noise_override(W.NoiseStream(9))
     try:
         y = blk(xq, input_kv=xkv, state_manager=sm, mask=True)
-        gy = torch.from_numpy(W.make_input(tuple(y.shape), 8, "gy")).cuda()
+        gy = torch.from_numpy(W.make_input(tuple(y.shape), 8, "gy")).to(device)
         kl = sm.get_kl_loss()
         ((y * gy).sum() + 0.5 * kl).backward()
     finally:
@@ -156,3 +169,18 @@ def test_single_block_bf16_within_stated_tolerance_of_reference_fixture(name):
     assert rel_err(xq.grad, g["dxq"]) < BF16_VS_FP32
     if kw["is_cross"]:
         assert rel_err(xkv.grad, g["dxkv"]) < BF16_VS_FP32
+
+
+@pytest.mark.parametrize("name", list(BLOCK_FIXTURES))
+def test_single_block_bf16_tight_against_emulation_of_the_rounding_points(name):
+    g, kw, blk, y, kl, xq, xkv = _block_on_gpu(name, "bf16")
+    with calm.backend.use_backend(EmulatedBackend()):
+        _, _, blk_e, y_e, kl_e, xq_e, xkv_e = _block_on_gpu(name, "bf16", device="cpu")
+    assert rel_err(y, y_e) < BF16_VS_EMULATION_BLOCK
+    assert rel_err(xq.grad, xq_e.grad) < 3 * BF16_VS_EMULATION_BLOCK
+    if kw["is_cross"]:
+        assert rel_err(xkv.grad, xkv_e.grad) < 3 * BF16_VS_EMULATION_BLOCK
+    pe = dict(blk_e.named_parameters())
+    for n, p in blk.named_parameters():
+        if p.numel() >= 4096:                          # matrices; the small vectors are sums with heavy cancellation
+            assert rel_err(p.grad, pe[n].grad) < 5 * BF16_VS_EMULATION_BLOCK, n
