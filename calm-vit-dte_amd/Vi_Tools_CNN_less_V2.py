@@ -89,14 +89,14 @@ class LayerNorm(torch.nn.Module):
         self.eps = eps
         self.normalized_shape = (dim,)
 
-    def forward(self, x):
-        return ops.layer_norm(x, self.weight, self.eps)
+    def forward(self, x, gemm_only=False):
+        return ops.LayerNormFn.apply(x, self.weight, self.eps, gemm_only)
 
     def with_skip(self, x):
         """(LayerNorm(x), x) — take the second value for the residual path that bypasses the norm: the two input
         gradients are then summed inside the LayerNorm backward kernel (ops.LayerNormSkipFn)."""
         if not (ops.FUSE_LN_SKIP and torch.is_grad_enabled() and x.requires_grad):
-            return self.forward(x), x
+            return self.forward(x, gemm_only=True), x
         return ops.LayerNormSkipFn.apply(x, self.weight, self.eps)
 
 
@@ -264,7 +264,7 @@ class VMLA_Block(torch.nn.Module):
     def _forward(self, input_q, input_kv, state_manager):
         H = self.heads
         xq, residual = self.ln_q.with_skip(input_q)                      # 209-215 (residual = input_q)
-        xkv = xq if input_kv is None else self.ln_kv(input_kv)
+        xkv = xq if input_kv is None else self.ln_kv(input_kv, gemm_only=True)
         qz = qr = xq
         kz = vz = kr = xkv
         if self.reduce:
@@ -309,7 +309,7 @@ class VMLA_Block(torch.nn.Module):
                 residual = self.input_proj(residual)
         x = self.out_proj(x, ls=self.ls_att, residual=residual)          # 300, 309
         if self.mlp is None:                                             # 310-315
-            return self.ln_2(x)
+            return self.ln_2(x)                                          # block output: stays fp32
         y, x = self.ln_2.with_skip(x)
         l0, l3 = self.mlp[0], self.mlp[3]
         return ops.MlpFn.apply(y, l0.weight_orig, None, l3.weight_orig, None, self.ls_mlp, x,

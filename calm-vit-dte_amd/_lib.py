@@ -12,6 +12,8 @@ LIB_PATH = os.environ.get("CALM_VIT_LIB") or os.path.join(HERE, "libcalmvit_hip.
 
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 F32 = 0
+ST_F32, ST_BF16 = 0, 1   # storage type of a tensor in HBM (CALM_ST_*)
+E_INVAL, E_LAYOUT, E_UNSUPP = -1, -2, -3      # CALM_E_*
 ABI_VERSION = 4          # CALM_ABI_VERSION of include/calm_vit.h
 
 _p = C.c_void_p
@@ -37,6 +39,7 @@ class GemmArgs(C.Structure):
         ("n_group", _i32),
         ("A_group", _p * 4), ("B_group", _p * 4), ("C_group", _p * 4), ("inv_scale_group", _p * 4),
         ("workspace", _p), ("workspace_bytes", _i64),
+        ("a_type", _i32), ("b_type", _i32), ("c_type", _i32), ("aux_type", _i32), ("r_type", _i32), ("reserved_", _i32),
     ]
 
 
@@ -50,6 +53,11 @@ class OptimHparams(C.Structure):
     """struct calm_optim_hparams."""
     _fields_ = [("lr", _f32), ("beta1", _f32), ("beta2", _f32), ("eps", _f32), ("weight_decay", _f32),
                 ("max_norm", _f32), ("step", _i32)]
+
+
+class CastEntry(C.Structure):
+    """struct calm_cast_entry."""
+    _fields_ = [("src", _p), ("dst", _p), ("numel", _i64), ("chunk0", _i32), ("reserved", _i32)]
 
 
 class SnLayer(C.Structure):
@@ -69,8 +77,10 @@ SIGNATURES = {
     "calm_build_info": (C.c_char_p, []),
     "calm_gemm": (_i32, [C.POINTER(GemmArgs), _p]),
     "calm_gemm_workspace_bytes": (_i64, [C.POINTER(GemmArgs)]),
-    "calm_layernorm_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _f32, _p]),
-    "calm_layernorm_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
+    "calm_layernorm_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _f32, _i32, _p]),
+    "calm_layernorm_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    "calm_cast_chunk_elems": (_i32, []),
+    "calm_cast_bf16": (_i32, [_p, _p, _i32, _p]),
     "calm_rope_fwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "calm_rope_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "calm_softmax_fwd": (_i32, [_p, _i64, _i32, _p]),
@@ -99,7 +109,7 @@ SIGNATURES = {
     "calm_add": (_i32, [_p, _p, _p, _i64, _p]),
     "calm_gelu_bwd": (_i32, [_p, _p, _p, _i64, _p]),
     "calm_colsum": (_i32, [_p, _p, _i64, _i32, _p]),
-    "calm_row_scale": (_i32, [_p, _p, _p, _i32, _i32, _p]),
+    "calm_row_scale": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
     "calm_mean_seq_fwd": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "calm_mean_seq_bwd": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
 }

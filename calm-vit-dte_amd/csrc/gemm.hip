@@ -46,6 +46,10 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
     if (!a || !a->A || !a->B || !a->C) return CALM_E_INVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch0 <= 0 || a->batch1 <= 0) return CALM_E_INVAL;
     if (a->dtype != CALM_F32 && a->dtype != CALM_BF16 && a->dtype != CALM_BF16X3) return CALM_E_UNSUPP;
+    for (int t : {a->a_type, a->b_type, a->c_type, a->aux_type, a->r_type})
+        if (t != CALM_ST_F32 && t != CALM_ST_BF16) return CALM_E_INVAL;
+    const bool any_bf16_tensor = a->a_type || a->b_type || a->c_type || a->aux_type || a->r_type;
+    if (any_bf16_tensor && a->dtype != CALM_BF16) return CALM_E_UNSUPP;       // bf16 tensors: bf16 matrix pipe only
     if (a->a_rs != 1 && a->a_cs != 1) return CALM_E_LAYOUT;
     if (a->b_rs != 1 && a->b_cs != 1) return CALM_E_LAYOUT;
     // the staging cursors address a tile with 32-bit byte offsets from a per-tile base: 255 rows x stride x 4 B < 2^32
@@ -64,34 +68,40 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
     hipStream_t s = as_stream(stream);
 
     GemmP p;
-    p.A = (const float*)a->A; p.B = (const float*)a->B; p.C = (float*)a->C;
+    p.A = a->A; p.B = a->B; p.C = a->C;
+    p.a_type = a->a_type; p.b_type = a->b_type; p.c_type = a->c_type; p.aux_type = a->aux_type; p.r_type = a->r_type;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.batch1 = a->batch1;
     p.a_rs = a->a_rs; p.a_cs = a->a_cs; p.a_b0 = a->a_b0; p.a_b1 = a->a_b1;
     p.b_rs = a->b_rs; p.b_cs = a->b_cs; p.b_b0 = a->b_b0; p.b_b1 = a->b_b1;
     p.c_rs = a->c_rs; p.c_b0 = a->c_b0; p.c_b1 = a->c_b1;
     p.alpha = a->alpha; p.inv_scale = a->inv_scale; p.bias = a->bias; p.col_scale = a->col_scale;
-    p.residual = (const float*)a->residual; p.r_rs = a->r_rs; p.r_b0 = a->r_b0; p.r_b1 = a->r_b1;
-    p.C_pre = (float*)a->C_pre; p.aux = (const float*)a->aux;
+    p.residual = a->residual; p.r_rs = a->r_rs; p.r_b0 = a->r_b0; p.r_b1 = a->r_b1;
+    p.C_pre = a->C_pre; p.aux = a->aux;
     p.act = a->act; p.accumulate = a->accumulate;
     p.n_group = a->n_group;
     p.reduce_group = a->n_group && a->reduce_batch;
     for (int g = 0; g < 4; ++g) {
         const bool on = g < a->n_group;
-        p.Ag[g] = on ? (const float*)a->A_group[g] : nullptr;
-        p.Bg[g] = on ? (const float*)a->B_group[g] : nullptr;
-        p.Cg[g] = on ? (float*)a->C_group[g] : nullptr;
+        p.Ag[g] = on ? a->A_group[g] : nullptr;
+        p.Bg[g] = on ? a->B_group[g] : nullptr;
+        p.Cg[g] = on ? a->C_group[g] : nullptr;
         p.Sg[g] = on ? a->inv_scale_group[g] : nullptr;
     }
     const int batch = a->batch0 * a->batch1;
     const bool akc = a->a_cs == 1;
     const bool bkc = a->b_cs == 1;
-    bool vec = aligned16(a->A) && aligned16(a->B) && mult4(a->a_b0) && mult4(a->a_b1) && mult4(a->b_b0) &&
-               mult4(a->b_b1);
+    // 16-byte staging vectors hold 4 fp32 or 8 bf16 elements: sizes / strides of an operand must be multiples of that
+    const int64_t ea = a->a_type == CALM_ST_BF16 ? 7 : 3, eb = a->b_type == CALM_ST_BF16 ? 7 : 3;
+    auto mult = [](int64_t x, int64_t mask) { return (x & mask) == 0; };
+    bool vec = aligned16(a->A) && aligned16(a->B) && mult(a->a_b0, ea) && mult(a->a_b1, ea) && mult(a->b_b0, eb) &&
+               mult(a->b_b1, eb);
     for (int g = 0; g < a->n_group; ++g) vec = vec && aligned16(a->A_group[g]) && aligned16(a->B_group[g]);
-    vec = vec && (akc ? (mult4(a->K) && mult4(a->a_rs)) : (mult4(a->M) && mult4(a->a_cs)));
-    vec = vec && (bkc ? (mult4(a->K) && mult4(a->b_rs)) : (mult4(a->N) && mult4(a->b_cs)));
-    // bf16-operand kernels need the 16-byte staging path; anything else runs on the exact fp32 kernels
+    vec = vec && (akc ? (mult(a->K, ea) && mult(a->a_rs, ea)) : (mult(a->M, ea) && mult(a->a_cs, ea)));
+    vec = vec && (bkc ? (mult(a->K, eb) && mult(a->b_rs, eb)) : (mult(a->N, eb) && mult(a->b_cs, eb)));
+    // bf16-operand kernels need the 16-byte staging path; anything else runs on the exact fp32 kernels — which
+    // only read fp32 tensors: a bf16 tensor in a launch that cannot be vectorised is the caller's layout error
+    if (!vec && any_bf16_tensor) return CALM_E_LAYOUT;
     const int family = vec ? a->dtype : CALM_F32;
     const int bk = family == CALM_F32 ? BK : CK;
     p.kpb = (a->K + bk - 1) / bk;
@@ -179,6 +189,7 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
     } else {
         p.kb_total = batch * p.kpb;
     }
+    if (p.atomic && a->c_type != CALM_ST_F32) return CALM_E_UNSUPP;            // k-slices combine in fp32
     if (p.slices_per_batch) {
         p.kb_per_z = (p.kpb + nsplit - 1) / nsplit;
         p.slices_per_batch = (p.kpb + p.kb_per_z - 1) / p.kb_per_z;      // no empty trailing slices
@@ -212,7 +223,7 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
         p.ws = (float*)a->workspace;
     } else if (p.atomic && !a->accumulate) {
         for (int g = 0; g < n_out; ++g) {
-            float* out = p.slices_per_batch ? p.Cg[g] : p.C;
+            float* out = (float*)(p.slices_per_batch ? p.Cg[g] : p.C);
             hipError_t e;
             if (a->c_rs == a->N) e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)a->M * a->N, s);
             else e = hipMemset2DAsync(out, sizeof(float) * a->c_rs, 0, sizeof(float) * a->N, a->M, s);
@@ -231,8 +242,8 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
 
     ReduceP q;
     q.ws = p.ws; q.ws_slice = p.ws_slice; q.nslices = slices_per_out;
-    q.C = p.C; q.c_b0 = a->c_b0; q.c_rs = a->c_rs;
-    for (int g = 0; g < 4; ++g) q.Cg[g] = p.slices_per_batch ? p.Cg[g] : nullptr;
+    q.C = (float*)p.C; q.c_b0 = a->c_b0; q.c_rs = a->c_rs;
+    for (int g = 0; g < 4; ++g) q.Cg[g] = p.slices_per_batch ? (float*)p.Cg[g] : nullptr;
     q.M = a->M; q.N = a->N; q.accumulate = a->accumulate;
     const long total = (long)a->M * a->N;
     const int gx = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);

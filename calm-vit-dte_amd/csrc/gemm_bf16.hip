@@ -4,8 +4,10 @@
 namespace calm_gemm_detail {
 
 // =====================================================================================================
-// bf16-operand GEMM family: tensors stay fp32 in HBM; operands are converted to bf16 while being staged
-// into LDS and multiplied on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate) with fp32 accumulation.
+// bf16-operand GEMM family: operands are multiplied on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate) with fp32
+// accumulation.  Each operand tensor is either fp32 in HBM — converted to bf16 while being staged into LDS — or
+// already bf16 in HBM (activations and the per-step weight copies of the bf16 pipeline: half the bytes per staged
+// element, no conversion; template parameters TA / TB).
 //   NPASS == 1: plain bf16 operands                  (what autocast(bfloat16) computes for Linear/matmul)
 //   NPASS == 3: split a = hi + lo (both bf16); acc += hi*hi + hi*lo + lo*hi   ("bf16x3": products accurate to
 //               ~2^-17 relative, i.e. fp32-level results at a fraction of the fp32-MFMA time, because the
@@ -23,74 +25,8 @@ constexpr int KC_LD = 40;              // bf16 per row of a [row][k] image
 constexpr int MC_LD = 160;             // bf16 per k-row of a [k][row] image
 constexpr int PLANE = 128 * KC_LD;     // == 32 * MC_LD bf16 = 10240 B
 
-template <bool KC, int ROWS>
-__device__ __forceinline__ void c_load(const float* __restrict__ base, long rs, long cs, int row0, int nrows_all,
-                                       int k0, int K, f32x4 (&reg)[4]) {
-    const int tid = threadIdx.x;
-    const int nrows = min(nrows_all, row0 + ROWS);
-    if constexpr (KC) {
-        const int k = k0 + 4 * (tid & 7);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = row0 + (tid >> 3) + 32 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < nrows && k < K) v = *reinterpret_cast<const f32x4*>(base + (long)row * rs + k);
-            reg[i] = v;
-        }
-    } else {
-        const int row = row0 + 4 * (tid & 31);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + 4 * (tid >> 5) + j;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (row < nrows && k < K) v = *reinterpret_cast<const f32x4*>(base + (long)k * cs + row);
-            reg[j] = v;
-        }
-    }
-}
-
-// cursor form of c_load (see OperandCursor): row addresses once per (tile, batch entry), clamped edge rows,
-// unconditional 16-byte loads for full k-blocks
-template <bool KC, int ROWS>
-struct CCursor {
-    const float* base;
-    unsigned off[4];
-    long step;
-    __device__ __forceinline__ void init(const float* origin, long rs, long cs, int row0, int nrows_all, int k0) {
-        const int tid = threadIdx.x;
-        const int last = min(nrows_all - row0, ROWS) - 1;
-        if constexpr (KC) {
-            base = origin + (long)row0 * rs + k0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) off[i] = (unsigned)(min((tid >> 3) + 32 * i, last) * rs + 4 * (tid & 7)) * 4u;
-            step = CK;
-        } else {
-            base = origin + (long)k0 * cs + row0;
-            const int row = min(4 * (tid & 31), last & ~3);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) off[j] = (unsigned)((4 * (tid >> 5) + j) * cs + row) * 4u;
-            step = CK * cs;
-        }
-    }
-    template <bool FULL>
-    __device__ __forceinline__ void load(int k_left, f32x4 (&reg)[4]) {
-        const int tid = threadIdx.x;
-        const char* b = reinterpret_cast<const char*>(base);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            f32x4 v;
-            if constexpr (FULL) {
-                v = *reinterpret_cast<const f32x4*>(b + off[i]);
-            } else {
-                const int k = KC ? 4 * (tid & 7) : 4 * (tid >> 5) + i;
-                v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (k < k_left) v = *reinterpret_cast<const f32x4*>(b + off[i]);
-            }
-            reg[i] = v;
-        }
-        base += step;
-    }
-};
+constexpr int MC_LDW = 288;                  // bf16 per k-row of a 256-row [k][row] image (same bank residue as 160)
+constexpr int WPLANE_A = WBM * KC_LD;        // 20480 B (>= 32 * MC_LDW)
 
 template <int NPASS>
 __device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
@@ -101,21 +37,79 @@ __device__ __forceinline__ void split4(const f32x4& v, bf16x4& hi, bf16x4& lo) {
     }
 }
 
-template <bool KC, int NPASS>
-__device__ __forceinline__ void c_store(__bf16* __restrict__ hi_plane, __bf16* __restrict__ lo_plane,
-                                        const f32x4 (&reg)[4]) {
-    const int tid = threadIdx.x;
+// Staging cursor of one operand tile (see OperandCursor in gemm_f32.hip: row addresses once per (tile, batch entry),
+// edge rows clamped instead of masked, unconditional 16-byte loads for whole k-blocks), typed by the operand's
+// storage: T = float (4 elements per 16-byte vector, converted to bf16 on the way into LDS) or __bf16 (8 per vector,
+// stored as loaded).  MAPROWS = rows of the thread map (128 or 256), LIVE = rows of the tile that exist (96 for the B
+// side of the 128x96 tile), LDMC = row stride of the [k][row] image.
+template <typename T, bool KC, int MAPROWS, int LIVE, int THREADS, int LDMC>
+struct TCursor {
+    static constexpr int EPV = 16 / (int)sizeof(T);
+    static constexpr int NV = MAPROWS * CK / (EPV * THREADS);   // 16-byte vectors per thread per k-tile
+    static constexpr int VPR = CK / EPV;                        // KC: vectors per row
+    static constexpr int RPP = THREADS / VPR;                   // KC: rows per pass
+    static constexpr int LPR = MAPROWS / EPV;                   // MC: threads across the rows of one k
+    static_assert(NV >= 1 && NV * EPV * THREADS == MAPROWS * CK, "thread map must tile the operand exactly");
+    typedef typename std::conditional<sizeof(T) == 4, f32x4, bf16x8>::type vec_t;
+    const T* base;
+    unsigned off[NV];
+    long step;
+    __device__ __forceinline__ void init(const T* origin, long rs, long cs, int row0, int nrows_all, int k0) {
+        const int tid = threadIdx.x;
+        const int last = min(nrows_all - row0, LIVE) - 1;
+        if constexpr (KC) {
+            base = origin + (long)row0 * rs + k0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        bf16x4 hi, lo;
-        split4<NPASS>(reg[i], hi, lo);
-        int off;
-        if constexpr (KC) off = ((tid >> 3) + 32 * i) * KC_LD + 4 * (tid & 7);          // [row][k]
-        else off = (4 * (tid >> 5) + i) * MC_LD + 4 * (tid & 31);                       // [k][row]
-        *reinterpret_cast<bf16x4*>(hi_plane + off) = hi;
-        if constexpr (NPASS == 3) *reinterpret_cast<bf16x4*>(lo_plane + off) = lo;
+            for (int i = 0; i < NV; ++i)
+                off[i] = (unsigned)(min((tid / VPR) + RPP * i, last) * rs + EPV * (tid % VPR)) * (unsigned)sizeof(T);
+            step = CK;
+        } else {
+            base = origin + (long)k0 * cs + row0;
+            const int row = min(EPV * (tid % LPR), last & ~(EPV - 1));      // rows come in aligned groups of EPV
+#pragma unroll
+            for (int j = 0; j < NV; ++j) off[j] = (unsigned)((NV * (tid / LPR) + j) * cs + row) * (unsigned)sizeof(T);
+            step = CK * cs;
+        }
     }
-}
+    template <bool FULL>
+    __device__ __forceinline__ void load(int k_left, vec_t (&reg)[NV]) {
+        const int tid = threadIdx.x;
+        const char* b = reinterpret_cast<const char*>(base);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            vec_t v;
+            if constexpr (FULL) {
+                v = *reinterpret_cast<const vec_t*>(b + off[i]);
+            } else {
+                const int k = KC ? EPV * (tid % VPR) : NV * (tid / LPR) + i;
+                v = vec_t{};
+                if (k < k_left) v = *reinterpret_cast<const vec_t*>(b + off[i]);
+            }
+            reg[i] = v;
+        }
+        base += step;
+    }
+    template <int NPASS>
+    __device__ __forceinline__ void store(__bf16* __restrict__ hi_plane, __bf16* __restrict__ lo_plane,
+                                          const vec_t (&reg)[NV]) const {
+        const int tid = threadIdx.x;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int o;
+            if constexpr (KC) o = ((tid / VPR) + RPP * i) * KC_LD + EPV * (tid % VPR);          // [row][k]
+            else o = (NV * (tid / LPR) + i) * LDMC + EPV * (tid % LPR);                          // [k][row]
+            if constexpr (sizeof(T) == 4) {
+                bf16x4 hi, lo;
+                split4<NPASS>(reg[i], hi, lo);
+                *reinterpret_cast<bf16x4*>(hi_plane + o) = hi;
+                if constexpr (NPASS == 3) *reinterpret_cast<bf16x4*>(lo_plane + o) = lo;
+            } else {
+                static_assert(sizeof(T) == 4 || NPASS == 1, "the hi/lo split needs fp32 operands");
+                *reinterpret_cast<bf16x8*>(hi_plane + o) = reg[i];
+            }
+        }
+    }
+};
 
 // MFMA A/B fragment (8 consecutive k for row `rowbase + (lane&31)`, k = 16*s + 8*(lane>>5) + 0..7)
 template <bool KC, int LD = MC_LD>
@@ -135,7 +129,7 @@ __device__ __forceinline__ bf16x8 c_frag(const __bf16* __restrict__ plane, int r
     }
 }
 
-template <bool AKC, bool BKC, int NPASS, int BN_>
+template <typename TA, typename TB, bool AKC, bool BKC, int NPASS, int BN_>
 __global__ __launch_bounds__(NTHREADS, NPASS == 3 ? 2 : CALM_GEMM_BF16_WAVES) void gemm_bf16c_kernel(const GemmP p) {
     constexpr int WN = BN_ == 128 ? 2 : 1;
     constexpr int MT = BN_ == 128 ? 2 : 1;
@@ -176,9 +170,12 @@ __global__ __launch_bounds__(NTHREADS, NPASS == 3 ? 2 : CALM_GEMM_BF16_WAVES) vo
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    f32x4 ra[4], rb[4];
-    CCursor<AKC, BM> ca;
-    CCursor<BKC, BN_> cb;
+    typedef TCursor<TA, AKC, BM, BM, NTHREADS, MC_LD> CurA;
+    typedef TCursor<TB, BKC, BM, BN_, NTHREADS, MC_LD> CurB;
+    typename CurA::vec_t ra[CurA::NV];
+    typename CurB::vec_t rb[CurB::NV];
+    CurA ca;
+    CurB cb;
     // one copy of the k-loop per case (whole k-tiles / tailed K): see OperandCursor::load
     auto k_loop = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
@@ -188,16 +185,16 @@ __global__ __launch_bounds__(NTHREADS, NPASS == 3 ? 2 : CALM_GEMM_BF16_WAVES) vo
         const int k0 = (kb - b * p.kpb) * CK;
         if (b != cur_b) {
             const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
-            ca.init(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, k0);
-            cb.init(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
+            ca.init(operand_base<TA>(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, k0);
+            cb.init(operand_base<TB>(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
             cur_b = b;
         }
         ca.template load<FULL>(p.K - k0, ra);
         cb.template load<FULL>(p.K - k0, rb);
     };
     auto stash = [&](int st) {
-        c_store<AKC, NPASS>(lds[st][0][0], lds[st][0][NPL - 1], ra);
-        c_store<BKC, NPASS>(lds[st][1][0], lds[st][1][NPL - 1], rb);
+        ca.template store<NPASS>(lds[st][0][0], lds[st][0][NPL - 1], ra);
+        cb.template store<NPASS>(lds[st][1][0], lds[st][1][NPL - 1], rb);
     };
 
     int buf = 0;
@@ -242,73 +239,14 @@ __global__ __launch_bounds__(NTHREADS, NPASS == 3 ? 2 : CALM_GEMM_BF16_WAVES) vo
     };
     if (p.K % CK == 0) k_loop(std::true_type{});
     else k_loop(std::false_type{});
-    gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
+    gemm_epilogue<MT, NT, true>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
 }
 
 // ---- wide tile of the bf16-operand family: 256x128x32 per 512-thread workgroup (8 waves as 4x2, each 64x64) ----
 // The 128-row tiles above are bound by re-reading the fp32 operand panels from L2 / Infinity Cache (32 flop per
 // byte staged); 256 rows raise that to 42.7.  60 KB LDS, <=128 VGPRs: two workgroups (16 waves) per CU.  Used for
 // the data-parallel launches (forward, data gradients) with enough tiles to fill the chip; NPASS == 1 only.
-constexpr int MC_LDW = 288;                  // bf16 per k-row of a 256-row [k][row] image (same bank residue as 160)
-constexpr int WPLANE_A = WBM * KC_LD;        // 20480 B (>= 32 * MC_LDW)
-
-template <bool KC, int ROWS>
-struct WCursor {
-    static constexpr int NV = ROWS * CK / (4 * WTHREADS);     // 16-byte vectors per thread per k-tile (4 or 2)
-    static constexpr int LD = ROWS == WBM ? MC_LDW : MC_LD;
-    const float* base;
-    unsigned off[NV];
-    long step;
-    __device__ __forceinline__ void init(const float* origin, long rs, long cs, int row0, int nrows_all, int k0) {
-        const int tid = threadIdx.x;
-        const int last = min(nrows_all - row0, ROWS) - 1;
-        if constexpr (KC) {
-            base = origin + (long)row0 * rs + k0;
-#pragma unroll
-            for (int i = 0; i < NV; ++i) off[i] = (unsigned)(min((tid >> 3) + 64 * i, last) * rs + 4 * (tid & 7)) * 4u;
-            step = CK;
-        } else {
-            constexpr int LPR = ROWS / 4;                     // threads across the rows
-            base = origin + (long)k0 * cs + row0;
-            const int row = min(4 * (tid % LPR), last & ~3);
-#pragma unroll
-            for (int j = 0; j < NV; ++j) off[j] = (unsigned)((NV * (tid / LPR) + j) * cs + row) * 4u;
-            step = CK * cs;
-        }
-    }
-    template <bool FULL>
-    __device__ __forceinline__ void load(int k_left, f32x4 (&reg)[NV]) {
-        const int tid = threadIdx.x;
-        const char* b = reinterpret_cast<const char*>(base);
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            f32x4 v;
-            if constexpr (FULL) {
-                v = *reinterpret_cast<const f32x4*>(b + off[i]);
-            } else {
-                const int k = KC ? 4 * (tid & 7) : NV * (tid / (ROWS / 4)) + i;
-                v = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (k < k_left) v = *reinterpret_cast<const f32x4*>(b + off[i]);
-            }
-            reg[i] = v;
-        }
-        base += step;
-    }
-    __device__ __forceinline__ void store(__bf16* __restrict__ plane, const f32x4 (&reg)[NV]) const {
-        const int tid = threadIdx.x;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            bf16x4 hi, lo;
-            split4<1>(reg[i], hi, lo);
-            int off;
-            if constexpr (KC) off = ((tid >> 3) + 64 * i) * KC_LD + 4 * (tid & 7);
-            else off = (NV * (tid / (ROWS / 4)) + i) * LD + 4 * (tid % (ROWS / 4));
-            *reinterpret_cast<bf16x4*>(plane + off) = hi;
-        }
-    }
-};
-
-template <bool AKC, bool BKC>
+template <typename TA, typename TB, bool AKC, bool BKC>
 __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) {
     constexpr int MT = 2, NT = 2;
     __shared__ __attribute__((aligned(16))) __bf16 lds_a[2][WPLANE_A];
@@ -345,9 +283,12 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    WCursor<AKC, WBM> ca;
-    WCursor<BKC, WBN> cb;
-    f32x4 ra[WCursor<AKC, WBM>::NV], rb[WCursor<BKC, WBN>::NV];
+    typedef TCursor<TA, AKC, WBM, WBM, WTHREADS, MC_LDW> CurA;
+    typedef TCursor<TB, BKC, WBN, WBN, WTHREADS, MC_LD> CurB;
+    CurA ca;
+    CurB cb;
+    typename CurA::vec_t ra[CurA::NV];
+    typename CurB::vec_t rb[CurB::NV];
     auto k_loop = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     int cur_b = -1;
@@ -356,8 +297,8 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
         const int k0 = (kb - b * p.kpb) * CK;
         if (b != cur_b) {
             const int b0 = b / p.batch1, b1 = b - b0 * p.batch1;
-            ca.init(operand_base(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, k0);
-            cb.init(operand_base(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
+            ca.init(operand_base<TA>(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, k0);
+            cb.init(operand_base<TB>(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
             cur_b = b;
         }
         ca.template load<FULL>(p.K - k0, ra);
@@ -367,8 +308,8 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
     int buf = 0;
     if (kb_begin < kb_end) {
         fetch(kb_begin);
-        ca.store(lds_a[0], ra);
-        cb.store(lds_b[0], rb);
+        ca.template store<1>(lds_a[0], lds_a[0], ra);
+        cb.template store<1>(lds_b[0], lds_b[0], rb);
     }
     __syncthreads();
 
@@ -390,8 +331,8 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         if (more) {
-            ca.store(lds_a[buf ^ 1], ra);
-            cb.store(lds_b[buf ^ 1], rb);
+            ca.template store<1>(lds_a[buf ^ 1], lds_a[buf ^ 1], ra);
+            cb.template store<1>(lds_b[buf ^ 1], lds_b[buf ^ 1], rb);
         }
         __syncthreads();
         buf ^= 1;
@@ -399,38 +340,48 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
     };
     if (p.K % CK == 0) k_loop(std::true_type{});
     else k_loop(std::false_type{});
-    gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
+    gemm_epilogue<MT, NT, true>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
 }
 
-int launch_wide(const GemmP& p, dim3 grid, bool akc, bool bkc, hipStream_t s) {
-    if (akc && bkc) hipLaunchKernelGGL((gemm_bf16w_kernel<true, true>), grid, dim3(WTHREADS), 0, s, p);
-    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16w_kernel<true, false>), grid, dim3(WTHREADS), 0, s, p);
-    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf16w_kernel<false, true>), grid, dim3(WTHREADS), 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16w_kernel<false, false>), grid, dim3(WTHREADS), 0, s, p);
+// ---- launchers: operand storage types (fp32 / bf16 in HBM) x operand layouts -----------------------------------------
+template <typename TA, typename TB>
+int launch_wide_t(const GemmP& p, dim3 grid, bool akc, bool bkc, hipStream_t s) {
+    if (akc && bkc) hipLaunchKernelGGL((gemm_bf16w_kernel<TA, TB, true, true>), grid, dim3(WTHREADS), 0, s, p);
+    else if (akc && !bkc) hipLaunchKernelGGL((gemm_bf16w_kernel<TA, TB, true, false>), grid, dim3(WTHREADS), 0, s, p);
+    else if (!akc && bkc) hipLaunchKernelGGL((gemm_bf16w_kernel<TA, TB, false, true>), grid, dim3(WTHREADS), 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16w_kernel<TA, TB, false, false>), grid, dim3(WTHREADS), 0, s, p);
     CALM_LAUNCH_CHECK();
     return 0;
 }
 
-template <bool AKC, bool BKC, int NPASS>
+template <typename TA, typename TB, bool AKC, bool BKC, int NPASS>
 int launch_c(const GemmP& p, dim3 grid, int bn, hipStream_t s) {
-    if (bn == 128) hipLaunchKernelGGL((gemm_bf16c_kernel<AKC, BKC, NPASS, 128>), grid, dim3(NTHREADS), 0, s, p);
-    else hipLaunchKernelGGL((gemm_bf16c_kernel<AKC, BKC, NPASS, 96>), grid, dim3(NTHREADS), 0, s, p);
+    if (bn == 128) hipLaunchKernelGGL((gemm_bf16c_kernel<TA, TB, AKC, BKC, NPASS, 128>), grid, dim3(NTHREADS), 0, s, p);
+    else hipLaunchKernelGGL((gemm_bf16c_kernel<TA, TB, AKC, BKC, NPASS, 96>), grid, dim3(NTHREADS), 0, s, p);
     CALM_LAUNCH_CHECK();
     return 0;
 }
 
-template <int NPASS>
+template <typename TA, typename TB, int NPASS>
 int launch_c_layout(const GemmP& p, dim3 grid, int bn, bool akc, bool bkc, hipStream_t s) {
-    if (akc && bkc) return launch_c<true, true, NPASS>(p, grid, bn, s);
-    if (akc && !bkc) return launch_c<true, false, NPASS>(p, grid, bn, s);
-    if (!akc && bkc) return launch_c<false, true, NPASS>(p, grid, bn, s);
-    return launch_c<false, false, NPASS>(p, grid, bn, s);
+    if (akc && bkc) return launch_c<TA, TB, true, true, NPASS>(p, grid, bn, s);
+    if (akc && !bkc) return launch_c<TA, TB, true, false, NPASS>(p, grid, bn, s);
+    if (!akc && bkc) return launch_c<TA, TB, false, true, NPASS>(p, grid, bn, s);
+    return launch_c<TA, TB, false, false, NPASS>(p, grid, bn, s);
 }
 
 int launch_bf16(const GemmP& p, dim3 grid, int bn, bool akc, bool bkc, int npass, hipStream_t s) {
-    if (npass == 3) return launch_c_layout<3>(p, grid, bn, akc, bkc, s);
-    return launch_c_layout<1>(p, grid, bn, akc, bkc, s);
+    if (npass == 3) return launch_c_layout<float, float, 3>(p, grid, bn, akc, bkc, s);      // hi/lo split: fp32 tensors only
+    if (p.a_type == CALM_ST_BF16 && p.b_type == CALM_ST_BF16) return launch_c_layout<__bf16, __bf16, 1>(p, grid, bn, akc, bkc, s);
+    if (p.a_type == CALM_ST_BF16) return launch_c_layout<__bf16, float, 1>(p, grid, bn, akc, bkc, s);
+    if (p.b_type == CALM_ST_BF16) return launch_c_layout<float, __bf16, 1>(p, grid, bn, akc, bkc, s);
+    return launch_c_layout<float, float, 1>(p, grid, bn, akc, bkc, s);
 }
-int launch_bf16_wide(const GemmP& p, dim3 grid, bool akc, bool bkc, hipStream_t s) { return launch_wide(p, grid, akc, bkc, s); }
+int launch_bf16_wide(const GemmP& p, dim3 grid, bool akc, bool bkc, hipStream_t s) {
+    if (p.a_type == CALM_ST_BF16 && p.b_type == CALM_ST_BF16) return launch_wide_t<__bf16, __bf16>(p, grid, akc, bkc, s);
+    if (p.a_type == CALM_ST_BF16) return launch_wide_t<__bf16, float>(p, grid, akc, bkc, s);
+    if (p.b_type == CALM_ST_BF16) return launch_wide_t<float, __bf16>(p, grid, akc, bkc, s);
+    return launch_wide_t<float, float>(p, grid, akc, bkc, s);
+}
 
 }  // namespace calm_gemm_detail

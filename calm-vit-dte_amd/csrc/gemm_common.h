@@ -30,7 +30,7 @@ constexpr int WTHREADS = 512, WBM = 256, WBN = 128;     // its wide tile
 #endif
 
 struct GemmP {
-    const float* A; const float* B; float* C;
+    const void* A; const void* B; void* C;      // element type per a_type / b_type / c_type (strides in elements)
     int M, N, K;
     int batch1;
     long a_rs, a_cs, a_b0, a_b1;
@@ -38,8 +38,8 @@ struct GemmP {
     long c_rs, c_b0, c_b1;
     float alpha;
     const float* inv_scale; const float* bias; const float* col_scale;
-    const float* residual; long r_rs, r_b0, r_b1;
-    float* C_pre; const float* aux;
+    const void* residual; long r_rs, r_b0, r_b1;
+    void* C_pre; const void* aux;               // C_pre has C's type
     int act, accumulate;
     int kpb;        // k-blocks per batch entry
     int kb_total;   // k-blocks in the whole reduction space walked by grid.y
@@ -49,15 +49,28 @@ struct GemmP {
     // grouped form: the b0 entries are separate allocations with their own spectral-norm scale
     int slices_per_batch;          // batched split-K: k-slices per batch entry (0: off)
     int n_group, reduce_group;     // reduce_group: the groups are summed into one C
-    const float* Ag[4]; const float* Bg[4]; float* Cg[4]; const float* Sg[4];
+    const void* Ag[4]; const void* Bg[4]; void* Cg[4]; const float* Sg[4];
     float* ws; long ws_slice;      // split launches with a workspace: slice blockIdx.y stores its partial tile at ws + y * ws_slice
+    int a_type, b_type, c_type, aux_type, r_type;      // CALM_ST_*: only the bf16-operand family takes bf16 tensors
 };
 
-// operand base of batch entry (b0, b1)
-__device__ __forceinline__ const float* operand_base(const float* base, const float* const (&tab)[4], int n_group,
-                                                     long s0, long s1, int b0, int b1) {
-    if (n_group && tab[0]) return tab[b0] + b1 * s1;
-    return base + b0 * s0 + b1 * s1;
+// operand base of batch entry (b0, b1); T = the operand's storage type
+template <typename T = float>
+__device__ __forceinline__ const T* operand_base(const void* base, const void* const (&tab)[4], int n_group,
+                                                 long s0, long s1, int b0, int b1) {
+    if (n_group && tab[0]) return reinterpret_cast<const T*>(tab[b0]) + b1 * s1;
+    return reinterpret_cast<const T*>(base) + b0 * s0 + b1 * s1;
+}
+// element access of the epilogue operands: TYPED = false (fp32 family) compiles to plain fp32 accesses
+template <bool TYPED>
+__device__ __forceinline__ float ld_elem(const void* base, long i, int type) {
+    if (TYPED && type == CALM_ST_BF16) return (float)reinterpret_cast<const __bf16*>(base)[i];
+    return reinterpret_cast<const float*>(base)[i];
+}
+template <bool TYPED>
+__device__ __forceinline__ void st_elem(void* base, long i, float v, int type) {
+    if (TYPED && type == CALM_ST_BF16) reinterpret_cast<__bf16*>(base)[i] = (__bf16)v;
+    else reinterpret_cast<float*>(base)[i] = v;
 }
 __device__ __forceinline__ float group_sigma(const GemmP& p, int g) { return p.Sg[g] ? p.Sg[g][0] : 1.f; }
 
@@ -84,7 +97,7 @@ __device__ __forceinline__ void for_each_subtile(F&& f, f32x16 (&acc)[MT][NT]) {
 
 // Shared epilogue: acc (32x32 MFMA C layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)) ->
 // scale, bias, optional pre-activation store, GELU / GELU', LayerScale, residual, accumulate or atomics.
-template <int MT, int NT>
+template <int MT, int NT, bool TYPED = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][NT], int m0, int n0, int wm, int wn,
                                               int r, int h, int z, int sgroup) {
     float scale = p.alpha;
@@ -92,15 +105,20 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
     const int zc = (p.atomic && !p.slices_per_batch) ? 0 : z;
     const int cb0 = zc / p.batch1, cb1 = zc - cb0 * p.batch1;
     const long coff = cb0 * p.c_b0 + cb1 * p.c_b1;
-    float* __restrict__ Cb = p.C + coff;
+    // bases as byte pointers + element offsets (the element size depends on the tensor's storage type)
+    const int csz = (TYPED && p.c_type == CALM_ST_BF16) ? 2 : 4;
+    char* __restrict__ Cb = reinterpret_cast<char*>(p.C) + coff * csz;
     if (p.n_group) {
         // independent groups: group cb0's sigma and output; grouped reduction: `sgroup` = last group of this k-range
         scale = scale / group_sigma(p, p.reduce_group ? sgroup : cb0);
-        if (!p.reduce_group && p.Cg[0]) Cb = p.Cg[cb0] + cb1 * p.c_b1;
+        if (!p.reduce_group && p.Cg[0]) Cb = reinterpret_cast<char*>(p.Cg[cb0]) + cb1 * p.c_b1 * csz;
     }
-    float* __restrict__ Pb = p.C_pre ? p.C_pre + coff : nullptr;
-    const float* __restrict__ Xb = p.aux ? p.aux + coff : nullptr;
-    const float* __restrict__ Rb = p.residual ? p.residual + cb0 * p.r_b0 + cb1 * p.r_b1 : nullptr;
+    char* __restrict__ Pb = p.C_pre ? reinterpret_cast<char*>(p.C_pre) + coff * csz : nullptr;
+    const char* __restrict__ Xb =
+        p.aux ? reinterpret_cast<const char*>(p.aux) + coff * ((TYPED && p.aux_type == CALM_ST_BF16) ? 2 : 4) : nullptr;
+    const char* __restrict__ Rb = p.residual ? reinterpret_cast<const char*>(p.residual) +
+                                                   (cb0 * p.r_b0 + cb1 * p.r_b1) * ((TYPED && p.r_type == CALM_ST_BF16) ? 2 : 4)
+                                             : nullptr;
 
     for_each_subtile<0, MT, NT>([&](int i, int j, const f32x16& a) {
         {
@@ -122,7 +140,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = row0 + (e & 3) + 8 * (e >> 2);
-                    if (row < p.M) atomicAdd(Cb + (long)row * p.c_rs + col, a[e] * scale);
+                    if (row < p.M) atomicAdd(reinterpret_cast<float*>(Cb) + (long)row * p.c_rs + col, a[e] * scale);
                 }
                 return;
             }
@@ -136,7 +154,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = row0 + (e & 3) + 8 * (e >> 2);
-                    if (row < p.M) Pb[(long)row * p.c_rs + col] = v[e];
+                    if (row < p.M) st_elem<TYPED>(Pb, (long)row * p.c_rs + col, v[e], p.c_type);
                 }
             }
             if (p.act == CALM_ACT_GELU) {
@@ -146,7 +164,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = row0 + (e & 3) + 8 * (e >> 2);
-                    t[e] = Xb[(long)(row < p.M ? row : 0) * p.c_rs + col];
+                    t[e] = ld_elem<TYPED>(Xb, (long)(row < p.M ? row : 0) * p.c_rs + col, p.aux_type);
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] *= gelu_erf_grad_f(t[e]);
@@ -157,7 +175,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = row0 + (e & 3) + 8 * (e >> 2);
-                    t[e] = Rb[(long)(row < p.M ? row : 0) * p.r_rs + col];
+                    t[e] = ld_elem<TYPED>(Rb, (long)(row < p.M ? row : 0) * p.r_rs + col, p.r_type);
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] += t[e];
@@ -166,7 +184,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     const int row = row0 + (e & 3) + 8 * (e >> 2);
-                    t[e] = Cb[(long)(row < p.M ? row : 0) * p.c_rs + col];
+                    t[e] = ld_elem<TYPED>(Cb, (long)(row < p.M ? row : 0) * p.c_rs + col, p.c_type);
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] += t[e];
@@ -174,7 +192,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int row = row0 + (e & 3) + 8 * (e >> 2);
-                if (row < p.M) Cb[(long)row * p.c_rs + col] = v[e];
+                if (row < p.M) st_elem<TYPED>(Cb, (long)row * p.c_rs + col, v[e], p.c_type);
             }
         }
     }, acc);

@@ -19,8 +19,12 @@ inline int grid_for(int64_t work_items, int per_block) {
 
 // ------------------------------------------------------------------ LayerNorm
 // one wave per row, rows grid-strided over waves
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+// Y16 / G16: the normalised output / the incoming gradient is a bf16 tensor (bf16 pipeline: the LayerNorm output only
+// feeds GEMMs, which round their operands to bf16 anyway — it is rounded once, here, when stored)
+template <bool Y16>
 __global__ __launch_bounds__(NT) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                    float* __restrict__ y, float* __restrict__ mean,
+                                                    void* __restrict__ y_, float* __restrict__ mean,
                                                     float* __restrict__ rstd, long rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
@@ -33,15 +37,19 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const float* __restrict__ x,
         float q = 0.f;
         for (int c = lane; c < D; c += 64) { const float d = xr[c] - mu; q += d * d; }
         const float rs = rsqrtf(wave_sum(q) / D + eps);
-        float* yr = y + row * D;
-        for (int c = lane; c < D; c += 64) yr[c] = (xr[c] - mu) * rs * w[c];
+        for (int c = lane; c < D; c += 64) {
+            const float o = (xr[c] - mu) * rs * w[c];
+            if constexpr (Y16) reinterpret_cast<__bf16*>(y_)[row * D + c] = (__bf16)o;
+            else reinterpret_cast<float*>(y_)[row * D + c] = o;
+        }
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     }
 }
 
 constexpr int LN_MAXC = 32;   // columns per lane kept in registers for dw (D <= 2048)
 
-__global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <bool G16>
+__global__ __launch_bounds__(NT) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                     const float* __restrict__ w, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, float* __restrict__ dx,
                                                     float* __restrict__ dw, const float* __restrict__ dx_add,
@@ -54,11 +62,14 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ dy
     for (int i = 0; i < LN_MAXC; ++i) dwacc[i] = 0.f;
     for (long row = wave; row < rows; row += nwaves) {
         const float* xr = x + row * D;
-        const float* gr = dy + row * D;
+        auto gr = [&](int c) -> float {
+            if constexpr (G16) return (float)reinterpret_cast<const __bf16*>(dy_)[row * D + c];
+            else return reinterpret_cast<const float*>(dy_)[row * D + c];
+        };
         const float mu = mean[row], rs = rstd[row];
         float c1 = 0.f, c2 = 0.f;
         for (int c = lane; c < D; c += 64) {
-            const float g = gr[c] * w[c];
+            const float g = gr(c) * w[c];
             const float xh = (xr[c] - mu) * rs;
             c1 += g; c2 += g * xh;
         }
@@ -69,7 +80,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ dy
             const int c = lane + 64 * i;
             if (c < D) {
                 const float xh = (xr[c] - mu) * rs;
-                const float gy = gr[c];
+                const float gy = gr(c);
                 dr[c] = rs * (gy * w[c] - c1 - xh * c2) + (dx_add ? dx_add[row * D + c] : 0.f);
                 dwacc[i] += gy * xh;
             }
@@ -90,9 +101,9 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ dy
 
 // Vectorised variants: the whole row lives in registers as NV float4 per lane (D <= 256*NV, D % 4 == 0),
 // one HBM pass per tensor, 16-byte coalesced accesses.
-template <int NV>
+template <int NV, bool Y16>
 __global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                        float* __restrict__ y, float* __restrict__ mean,
+                                                        void* __restrict__ y_, float* __restrict__ mean,
                                                         float* __restrict__ rstd, long rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
@@ -124,7 +135,6 @@ __global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const float* __restrict_
             }
         }
         const float rs = rsqrtf(wave_sum(q) / D + eps);
-        f32x4* yr = reinterpret_cast<f32x4*>(y + row * D);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c4 = lane + 64 * i;
@@ -132,15 +142,20 @@ __global__ __launch_bounds__(NT) void ln_fwd_vec_kernel(const float* __restrict_
                 f32x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (xv[i][e] - mu) * rs * wv[i][e];
-                yr[c4] = o;
+                if constexpr (Y16) {
+                    bf16x4 ob = {(__bf16)o[0], (__bf16)o[1], (__bf16)o[2], (__bf16)o[3]};
+                    reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(y_) + row * D)[c4] = ob;
+                } else {
+                    reinterpret_cast<f32x4*>(reinterpret_cast<float*>(y_) + row * D)[c4] = o;
+                }
             }
         }
         if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
     }
 }
 
-template <int NV>
-__global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <int NV, bool G16>
+__global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                         const float* __restrict__ w, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, float* __restrict__ dx,
                                                         float* __restrict__ dw, const float* __restrict__ dx_add,
@@ -158,7 +173,14 @@ __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const float* __restrict_
     }
     for (long row = wave; row < rows; row += nwaves) {
         const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
-        const f32x4* gr = reinterpret_cast<const f32x4*>(dy + row * D);
+        auto gr = [&](int c4) -> f32x4 {
+            if constexpr (G16) {
+                const bf16x4 g = reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(dy_) + row * D)[c4];
+                return (f32x4){(float)g[0], (float)g[1], (float)g[2], (float)g[3]};
+            } else {
+                return reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dy_) + row * D)[c4];
+            }
+        };
         const float mu = mean[row], rs = rstd[row];
         f32x4 xh[NV], gv[NV];
         float c1 = 0.f, c2 = 0.f;
@@ -167,7 +189,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const float* __restrict_
             const int c4 = lane + 64 * i;
             const bool in = c4 < nv4;
             const f32x4 xv = in ? xr[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
-            gv[i] = in ? gr[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            gv[i] = in ? gr(c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 xh[i][e] = in ? (xv[e] - mu) * rs : 0.f;
@@ -521,11 +543,15 @@ __global__ __launch_bounds__(CS_NT) void colsum_vec_kernel(const float* __restri
     }
 }
 
+template <bool O16>
 __global__ __launch_bounds__(NT) void row_scale_kernel(const float* __restrict__ x, const float* __restrict__ s,
-                                                       float* __restrict__ out, int rows, int cols) {
+                                                       void* __restrict__ out_, int rows, int cols) {
     const long total = (long)rows * cols;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT)
-        out[i] = x[i] * s[i / cols];
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const float v = x[i] * s[i / cols];
+        if constexpr (O16) reinterpret_cast<__bf16*>(out_)[i] = (__bf16)v;
+        else reinterpret_cast<float*>(out_)[i] = v;
+    }
 }
 
 __global__ __launch_bounds__(NT) void mean_seq_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
@@ -556,52 +582,69 @@ __global__ __launch_bounds__(NT) void mean_seq_bwd_kernel(const float* __restric
 
 extern "C" {
 
-int calm_layernorm_fwd(const float* x, const float* w, float* y, float* mean, float* rstd, int64_t rows, int32_t D,
-                       float eps, void* stream) {
+int calm_layernorm_fwd(const float* x, const float* w, void* y, float* mean, float* rstd, int64_t rows, int32_t D,
+                       float eps, int32_t y_type, void* stream) {
     if (!x || !w || !y || !mean || !rstd || rows <= 0 || D <= 0) return CALM_E_INVAL;
+    if (y_type != CALM_ST_F32 && y_type != CALM_ST_BF16) return CALM_E_INVAL;
+    const bool y16 = y_type == CALM_ST_BF16;
+    hipStream_t s = as_stream(stream);
+    const dim3 g(grid_for(rows, NT / 64)), b(NT);
     if ((D & 3) == 0 && D <= 256 * 5 && aligned16(x) && aligned16(y) && aligned16(w)) {
-        const dim3 g(grid_for(rows, NT / 64)), b(NT);
-        hipStream_t s = as_stream(stream);
         const int nv = (D / 4 + 63) / 64;
+#define LN_FWD(NVV)                                                                                                  \
+    do {                                                                                                             \
+        if (y16) hipLaunchKernelGGL((ln_fwd_vec_kernel<NVV, true>), g, b, 0, s, x, w, y, mean, rstd, (long)rows, D, eps); \
+        else hipLaunchKernelGGL((ln_fwd_vec_kernel<NVV, false>), g, b, 0, s, x, w, y, mean, rstd, (long)rows, D, eps);    \
+    } while (0)
         switch (nv) {
-            case 1: hipLaunchKernelGGL(ln_fwd_vec_kernel<1>, g, b, 0, s, x, w, y, mean, rstd, (long)rows, D, eps); break;
-            case 2: hipLaunchKernelGGL(ln_fwd_vec_kernel<2>, g, b, 0, s, x, w, y, mean, rstd, (long)rows, D, eps); break;
-            case 3: hipLaunchKernelGGL(ln_fwd_vec_kernel<3>, g, b, 0, s, x, w, y, mean, rstd, (long)rows, D, eps); break;
-            case 4: hipLaunchKernelGGL(ln_fwd_vec_kernel<4>, g, b, 0, s, x, w, y, mean, rstd, (long)rows, D, eps); break;
-            default: hipLaunchKernelGGL(ln_fwd_vec_kernel<5>, g, b, 0, s, x, w, y, mean, rstd, (long)rows, D, eps); break;
+            case 1: LN_FWD(1); break;
+            case 2: LN_FWD(2); break;
+            case 3: LN_FWD(3); break;
+            case 4: LN_FWD(4); break;
+            default: LN_FWD(5); break;
         }
+#undef LN_FWD
         CALM_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(grid_for(rows, NT / 64)), dim3(NT), 0, as_stream(stream), x, w, y, mean,
-                       rstd, (long)rows, D, eps);
+    if (y16) hipLaunchKernelGGL(ln_fwd_kernel<true>, g, b, 0, s, x, w, y, mean, rstd, (long)rows, D, eps);
+    else hipLaunchKernelGGL(ln_fwd_kernel<false>, g, b, 0, s, x, w, y, mean, rstd, (long)rows, D, eps);
     CALM_LAUNCH_CHECK();
     return 0;
 }
 
-int calm_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean, const float* rstd,
-                       float* dx, float* dw, const float* dx_add, int64_t rows, int32_t D, void* stream) {
+int calm_layernorm_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
+                       float* dx, float* dw, const float* dx_add, int64_t rows, int32_t D, int32_t dy_type,
+                       void* stream) {
     if (!dy || !x || !w || !mean || !rstd || !dx || !dw || rows <= 0 || D <= 0) return CALM_E_INVAL;
+    if (dy_type != CALM_ST_F32 && dy_type != CALM_ST_BF16) return CALM_E_INVAL;
     if (D > 64 * LN_MAXC) return CALM_E_UNSUPP;
+    const bool g16 = dy_type == CALM_ST_BF16;
     int g = grid_for(rows, NT / 64);
     if (g > 512) g = 512;
+    hipStream_t s = as_stream(stream);
+    const dim3 gd(g), b(NT);
     if ((D & 3) == 0 && D <= 256 * 5 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(w) &&
         aligned16(dx_add)) {
-        const dim3 gd(g), b(NT);
-        hipStream_t s = as_stream(stream);
         const int nv = (D / 4 + 63) / 64;
+#define LN_BWD(NVV)                                                                                                        \
+    do {                                                                                                                   \
+        if (g16) hipLaunchKernelGGL((ln_bwd_vec_kernel<NVV, true>), gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D); \
+        else hipLaunchKernelGGL((ln_bwd_vec_kernel<NVV, false>), gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D);    \
+    } while (0)
         switch (nv) {
-            case 1: hipLaunchKernelGGL(ln_bwd_vec_kernel<1>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D); break;
-            case 2: hipLaunchKernelGGL(ln_bwd_vec_kernel<2>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D); break;
-            case 3: hipLaunchKernelGGL(ln_bwd_vec_kernel<3>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D); break;
-            case 4: hipLaunchKernelGGL(ln_bwd_vec_kernel<4>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D); break;
-            default: hipLaunchKernelGGL(ln_bwd_vec_kernel<5>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D); break;
+            case 1: LN_BWD(1); break;
+            case 2: LN_BWD(2); break;
+            case 3: LN_BWD(3); break;
+            case 4: LN_BWD(4); break;
+            default: LN_BWD(5); break;
         }
+#undef LN_BWD
         CALM_LAUNCH_CHECK();
         return 0;
     }
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(g), dim3(NT), 0, as_stream(stream), dy, x, w, mean, rstd, dx, dw, dx_add,
-                       (long)rows, D);
+    if (g16) hipLaunchKernelGGL(ln_bwd_kernel<true>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D);
+    else hipLaunchKernelGGL(ln_bwd_kernel<false>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D);
     CALM_LAUNCH_CHECK();
     return 0;
 }
@@ -738,10 +781,13 @@ int calm_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* st
     return 0;
 }
 
-int calm_row_scale(const float* x, const float* s, float* out, int32_t rows, int32_t cols, void* stream) {
+int calm_row_scale(const float* x, const float* s, void* out, int32_t rows, int32_t cols, int32_t out_type,
+                   void* stream) {
     if (!x || !s || !out || rows <= 0 || cols <= 0) return CALM_E_INVAL;
-    hipLaunchKernelGGL(row_scale_kernel, dim3(grid_for((int64_t)rows * cols, NT)), dim3(NT), 0, as_stream(stream), x,
-                       s, out, rows, cols);
+    if (out_type != CALM_ST_F32 && out_type != CALM_ST_BF16) return CALM_E_INVAL;
+    const dim3 g(grid_for((int64_t)rows * cols, NT)), b(NT);
+    if (out_type == CALM_ST_BF16) hipLaunchKernelGGL(row_scale_kernel<true>, g, b, 0, as_stream(stream), x, s, out, rows, cols);
+    else hipLaunchKernelGGL(row_scale_kernel<false>, g, b, 0, as_stream(stream), x, s, out, rows, cols);
     CALM_LAUNCH_CHECK();
     return 0;
 }

@@ -141,9 +141,39 @@ __global__ __launch_bounds__(NT) void sn_bwd_apply(const float* __restrict__ G, 
         for (int r = threadIdx.x; r < rows; r += NT) d_ls[r] = rowdot[r];
 }
 
+// ---- per-step bf16 copies of all weights (bf16 pipeline) ------------------------------------------------------------
+constexpr int CAST_CHUNK = 16384;            // elements per work item (64 per thread)
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(NT) void cast_bf16_kernel(const calm_cast_entry* __restrict__ E, const int* __restrict__ chunk_entry) {
+    const calm_cast_entry e = E[chunk_entry[blockIdx.x]];
+    const long i0 = (long)(blockIdx.x - e.chunk0) * CAST_CHUNK;
+    const long i1 = min(i0 + (long)CAST_CHUNK, (long)e.numel);
+    __bf16* dst = reinterpret_cast<__bf16*>(e.dst);
+    if (((reinterpret_cast<uintptr_t>(e.src) & 15) | (reinterpret_cast<uintptr_t>(e.dst) & 7)) == 0) {
+        const long v1 = i0 + ((i1 - i0) & ~3L);
+        for (long i = i0 + 4 * threadIdx.x; i < v1; i += 4 * NT) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(e.src + i);
+            *reinterpret_cast<bf16x4*>(dst + i) = (bf16x4){(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+        }
+        for (long i = v1 + threadIdx.x; i < i1; i += NT) dst[i] = (__bf16)e.src[i];
+    } else {
+        for (long i = i0 + threadIdx.x; i < i1; i += NT) dst[i] = (__bf16)e.src[i];
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int32_t calm_cast_chunk_elems(void) { return CAST_CHUNK; }
+
+int calm_cast_bf16(const calm_cast_entry* entries_dev, const int32_t* chunk_entry_dev, int32_t n_chunks, void* stream) {
+    if (!entries_dev || !chunk_entry_dev || n_chunks <= 0) return CALM_E_INVAL;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(n_chunks), dim3(NT), 0, as_stream(stream), entries_dev, chunk_entry_dev);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
 
 int calm_sn_plan(const calm_sn_layer* layers, int32_t n, void* blob_host, calm_sn_plan_info* info) {
     if (!layers || n <= 0 || !info) return CALM_E_INVAL;

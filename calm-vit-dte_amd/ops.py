@@ -14,7 +14,8 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from .backend import ACT_GELU, ACT_GELU_BWD, ACT_NONE, get_backend
+from .backend import ACT_GELU, ACT_GELU_BWD, ACT_NONE, act_dtype, bf16_pipeline, get_backend
+from .spectral_norm import W16_ATTR
 
 # The reference calls the model under autocast(bfloat16) (distributed_trainer_cls.py:84): custom_fwd records the
 # autocast state of the forward call, custom_bwd re-establishes it around backward (autograd runs backward outside the
@@ -43,6 +44,17 @@ def draw_noise(like):
 
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
+
+
+def _wop(w):
+    """The GEMM operand for weight `w`: in the bf16 pipeline the bf16 copy made at the start of this forward
+    (spectral_norm._refresh_bf16_weights) — the product is the same as rounding the fp32 weight while it is staged —
+    when its rows can be staged as 16-byte bf16 vectors (in_features % 8 == 0)."""
+    if bf16_pipeline() and w.shape[-1] % 8 == 0:
+        w16 = getattr(w, W16_ATTR, None)
+        if w16 is not None and w16.shape == w.shape:
+            return w16
+    return w
 
 
 class _ZeroArena:
@@ -127,6 +139,8 @@ def _sn_wbwd(be, G, w, u, v, sigma, ls=None, defer=False):
 
 
 def _colsum(be, x2):
+    if x2.dtype != torch.float32:
+        x2 = x2.float()                     # bias gradients of bf16 tensors: not on the model's path (its MLPs have no bias)
     out = _zeros((x2.shape[1],), x2)
     be.colsum(x2, out, x2.shape[0], x2.shape[1])
     return out
@@ -134,16 +148,18 @@ def _colsum(be, x2):
 
 # ---------------------------------------------------------------------------------------
 class LayerNormFn(Function):
-    """LayerNorm(D, eps=1e-6, bias=False) (Vi_Tools:131-132,197,494)."""
+    """LayerNorm(D, eps=1e-6, bias=False) (Vi_Tools:131-132,197,494).  gemm_only: the output feeds nothing but GEMMs
+    (ln_q / ln_kv / ln_2 of a block) — the bf16 pipeline then stores it as bf16, rounded once here instead of every
+    time a GEMM stages a tile of it."""
 
     @staticmethod
     @_amp_fwd
-    def forward(ctx, x, w, eps):
+    def forward(ctx, x, w, eps, gemm_only=False):
         be = get_backend()
         x = _c(x)
         D = x.shape[-1]
         rows = x.numel() // D
-        y = torch.empty_like(x)
+        y = torch.empty(x.shape, dtype=act_dtype(D) if gemm_only else x.dtype, device=x.device)
         mean = torch.empty(rows, dtype=x.dtype, device=x.device)
         rstd = torch.empty_like(mean)
         be.layernorm_fwd(x, w, y, mean, rstd, rows, D, eps)
@@ -161,7 +177,7 @@ class LayerNormFn(Function):
         dx = torch.empty_like(x)
         dw = _zeros(w.shape, w)
         be.layernorm_bwd(dy, x, w, mean, rstd, dx, dw, x.numel() // D, D)
-        return dx, dw, None
+        return dx, dw, None, None
 
 
 class LayerNormSkipFn(Function):
@@ -177,7 +193,7 @@ class LayerNormSkipFn(Function):
         x = _c(x)
         D = x.shape[-1]
         rows = x.numel() // D
-        y = torch.empty_like(x)
+        y = torch.empty(x.shape, dtype=act_dtype(D), device=x.device)       # feeds GEMMs only (see LayerNormFn)
         mean = torch.empty(rows, dtype=x.dtype, device=x.device)
         rstd = torch.empty_like(mean)
         be.layernorm_fwd(x, w, y, mean, rstd, rows, D, eps)
@@ -214,12 +230,14 @@ class SNLinearFn(Function):
         K = x.shape[-1]
         N = w.shape[0]
         x2 = x.reshape(-1, K)
-        out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        wop = _wop(w)
+        out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
         pre = torch.empty_like(out) if act == ACT_GELU else None
         res2 = _c(residual).reshape(-1, N) if residual is not None else None
-        _lin_fwd(be, x2, w, sigma, out.view(-1, N), bias=bias, act=act, col_scale=ls, residual=res2,
+        _lin_fwd(be, x2, wop, sigma, out.view(-1, N), bias=bias, act=act, col_scale=ls, residual=res2,
                  pre=pre.view(-1, N) if pre is not None else None)
         ctx.act = act
+        ctx.wop = wop
         ctx.defer = _deferred(w)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
@@ -245,12 +263,12 @@ class SNLinearFn(Function):
         dW, d_ls = _sn_wbwd(be, G, w, u, v, sigma, ls, defer=ctx.defer)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x2)
+            dx = torch.empty_like(x2)                       # a bf16 input (LayerNorm output) gets a bf16 gradient
             if ls is not None:
-                wl = torch.empty_like(w)
+                wl = torch.empty_like(ctx.wop)
                 be.row_scale(w, ls, wl, N, K)
             else:
-                wl = w
+                wl = ctx.wop
             _lin_dgrad(be, dz, wl, sigma, dx)
             dx = dx.view(ctx.xshape)
         db = _colsum(be, dz) if ctx.has_bias else None
@@ -277,10 +295,12 @@ class SNLinearGroupFn(Function):
         assert all(w.shape == (N, K) for w in ws)
         x2 = x.reshape(-1, K)
         M = x2.shape[0]
-        outs = [torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device) for _ in range(n)]
-        be.gemm(x2, ws, [o.view(-1, N) for o in outs], M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), batch=(n, 1),
+        wops = [_wop(w) for w in ws]
+        outs = [torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device) for _ in range(n)]
+        be.gemm(x2, wops, [o.view(-1, N) for o in outs], M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), batch=(n, 1),
                 inv_scale=sigmas, split_k=1)
         ctx.n = n
+        ctx.wops = wops
         ctx.defer = [_deferred(w) for w in ws]
         ctx.xshape = x.shape
         ctx.save_for_backward(x2, *wuvs)
@@ -306,7 +326,7 @@ class SNLinearGroupFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)
-            be.gemm(dy2, ws, dx, M, K, N, (N, 1, 0, 0), (1, K, 0, 0), (K, 0, 0), batch=(n, 1), inv_scale=sigmas,
+            be.gemm(dy2, ctx.wops, dx, M, K, N, (N, 1, 0, 0), (1, K, 0, 0), (K, 0, 0), batch=(n, 1), inv_scale=sigmas,
                     reduce_batch=True, split_k=1)
             dx = dx.view(ctx.xshape)
         return (dx, *grads)
@@ -326,12 +346,15 @@ class MlpFn(Function):
         N = w2.shape[0]
         x2 = x.reshape(-1, K)
         M = x2.shape[0]
-        hp = torch.empty(M, Hd, dtype=x.dtype, device=x.device)
+        wop1, wop2 = _wop(w1), _wop(w2)
+        # hidden state and pre-activation feed GEMMs / the GELU' epilogue only: bf16 tensors in the bf16 pipeline
+        hp = torch.empty(M, Hd, dtype=act_dtype(Hd), device=x.device)
         hg = torch.empty_like(hp)
-        _lin_fwd(be, x2, w1, s1, hg, bias=b1, act=ACT_GELU, pre=hp)
-        out = torch.empty(x.shape[:-1] + (N,), dtype=x.dtype, device=x.device)
+        _lin_fwd(be, x2, wop1, s1, hg, bias=b1, act=ACT_GELU, pre=hp)
+        out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
         res2 = _c(residual).reshape(-1, N) if residual is not None else None
-        _lin_fwd(be, hg, w2, s2, out.view(-1, N), bias=b2, col_scale=ls, residual=res2)
+        _lin_fwd(be, hg, wop2, s2, out.view(-1, N), bias=b2, col_scale=ls, residual=res2)
+        ctx.wops = (wop1, wop2)
         ctx.has_b1, ctx.has_b2, ctx.has_res = b1 is not None, b2 is not None, residual is not None
         ctx.defer = (_deferred(w1), _deferred(w2))
         ctx.xshape = x.shape
@@ -351,11 +374,12 @@ class MlpFn(Function):
         _lin_wgrad(be, do2, hg, G2)
         dW2, d_ls = _sn_wbwd(be, G2, w2, u2, v2, s2, ls, defer=ctx.defer[1])
         db2 = _colsum(be, do2) if ctx.has_b2 else None
+        wop1, wop2 = ctx.wops
         if ls is not None:
-            w2l = torch.empty_like(w2)
+            w2l = torch.empty_like(wop2)
             be.row_scale(w2, ls, w2l, N, Hd)
         else:
-            w2l = w2
+            w2l = wop2
         dhp = torch.empty_like(hp)
         _lin_dgrad(be, do2, w2l, s2, dhp, act=ACT_GELU_BWD, aux=hp)
         G1 = _zeros_big(w1.shape, w1)
@@ -365,7 +389,7 @@ class MlpFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)
-            _lin_dgrad(be, dhp, w1, s1, dx)
+            _lin_dgrad(be, dhp, wop1, s1, dx)
             dx = dx.view(ctx.xshape)
         dres = dout if ctx.has_res else None
         return dx, dW1, db1, dW2, db2, d_ls, dres, None, None, None, None, None, None
@@ -382,9 +406,11 @@ class SeqLinearFn(Function):
         x = _c(x)
         B, S, D = x.shape
         S2 = w.shape[0]
-        out = torch.empty(B, S2, D, dtype=x.dtype, device=x.device)
-        be.gemm(w, x, out, S2, D, S, (S, 1, 0, 0), (1, D, S * D, 0), (D, S2 * D, 0), batch=(B, 1), inv_scale=sigma)
+        wop = _wop(w)
+        out = torch.empty(B, S2, D, dtype=torch.float32, device=x.device)
+        be.gemm(wop, x, out, S2, D, S, (S, 1, 0, 0), (1, D, S * D, 0), (D, S2 * D, 0), batch=(B, 1), inv_scale=sigma)
         ctx.defer = _deferred(w)
+        ctx.wop = wop
         ctx.save_for_backward(x, w, u, v, sigma)
         return out
 
@@ -401,7 +427,7 @@ class SeqLinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             # dX[b] = W^T dY[b] / sigma : A(m=s,k=s2) = W[s2,s]
-            be.gemm(w, dy, dx, S, D, S2, (1, S, 0, 0), (1, D, S2 * D, 0), (D, S * D, 0), batch=(B, 1),
+            be.gemm(ctx.wop, dy, dx, S, D, S2, (1, S, 0, 0), (1, D, S2 * D, 0), (D, S * D, 0), batch=(B, 1),
                     inv_scale=sigma)
         # G[s2,s] = sum_b sum_d dY[b,s2,d] X[b,s,d]
         G = _zeros_big(w.shape, w)

@@ -12,7 +12,9 @@ import math
 
 import torch
 
-from .backend import get_backend
+from .backend import bf16_pipeline, get_backend
+
+W16_ATTR = "_calm_w16"      # on a weight_orig Parameter: its bf16 copy for this step (bf16 pipeline), read by ops._wop
 
 _scope_depth = 0
 
@@ -58,6 +60,7 @@ class SpectralWeight(torch.nn.Module):
         if self._own_plan is None or self._own_plan.key != key:
             self._own_plan = be.sn_plan([t])
         be.sn_power_iter(self._own_plan, self.training)
+        _refresh_bf16_weights(self, [self])
         return self._sigma
 
 
@@ -133,5 +136,31 @@ def _batched_update(root):
         plan = be.sn_plan(tensors)
         root.__dict__["_sn_plan"] = plan
     be.sn_power_iter(plan, root.training)
+    _refresh_bf16_weights(root, layers)
     for m in layers:
         m._fresh = True
+
+
+def _refresh_bf16_weights(root, layers):
+    """bf16 pipeline: one launch rewrites the bf16 copy of every weight below `root` (W_orig rounded to nearest even —
+    what autocast's cast of a Linear weight does; sigma stays a fp32 epilogue factor).  The copies live in one flat
+    buffer per root; each weight_orig Parameter carries its view (W16_ATTR) for ops to use as the GEMM operand."""
+    if not bf16_pipeline():
+        return
+    be = get_backend()
+    ws = [m.weight_orig for m in layers]
+    key = tuple(w.data_ptr() for w in ws)
+    st = root.__dict__.get("_w16_state")
+    if st is None or st["key"] != key:
+        offs, n = [], 0
+        for w in ws:
+            offs.append(n)
+            n += (w.numel() + 7) & ~7                          # 16-byte aligned slices
+        flat = torch.empty(n, dtype=torch.bfloat16, device=ws[0].device)
+        views = [flat[o:o + w.numel()].view(w.shape) for o, w in zip(offs, ws)]
+        plan = be.cast_plan([(w.detach().reshape(-1), v.view(-1)) for w, v in zip(ws, views)])
+        st = {"key": key, "flat": flat, "views": views, "plan": plan}
+        root.__dict__["_w16_state"] = st
+    be.cast_run(st["plan"])
+    for w, v in zip(ws, st["views"]):
+        setattr(w, W16_ATTR, v)

@@ -15,7 +15,7 @@
  *  - return value: 0 = ok, <0 = invalid argument / unsupported shape (CALM_E_*),
  *    >0 = hipError_t of the failed launch.  No C++ exceptions cross the boundary.
  *  - NaN/Inf propagate (GradScaler's inf check relies on it, distributed_trainer_cls.py:88,93).
- *  - dtype of all tensors in this revision: fp32 (CALM_F32).
+ *  - tensors are fp32 unless an entry point takes a storage-type argument (CALM_ST_*; ABI v4: the bf16 pipeline).
  */
 #ifndef CALM_VIT_H
 #define CALM_VIT_H
@@ -38,6 +38,7 @@ extern "C" {
  *   CALM_BF16   operands rounded to bf16 in LDS, fp32 accumulate (what autocast(bfloat16) computes)
  *   CALM_BF16X3 operands split hi+lo bf16, 3 MFMA passes, fp32 accumulate: ~2^-17 relative product error */
 enum { CALM_F32 = 0, CALM_BF16 = 1, CALM_BF16X3 = 2 };
+enum { CALM_ST_F32 = 0, CALM_ST_BF16 = 1 };          /* storage type of a tensor in HBM */
 enum { CALM_ACT_NONE = 0, CALM_ACT_GELU = 1, CALM_ACT_GELU_BWD = 2 };
 
 int         calm_abi_version(void);
@@ -101,6 +102,16 @@ typedef struct calm_gemm_args {
     const float* inv_scale_group[4];
     void*        workspace;      /* optional (ABI v3): device scratch for split launches, see calm_gemm_workspace_bytes */
     int64_t      workspace_bytes;
+    /* ABI v4 — storage type of each tensor in HBM (CALM_ST_F32 / CALM_ST_BF16; strides stay in ELEMENTS of the tensor).
+     * bf16 tensors are accepted by the bf16 matrix pipe only (dtype == CALM_BF16): the bf16 pipeline keeps the
+     * activations that only GEMMs consume (LayerNorm outputs, MLP hidden states, attention outputs, their
+     * gradients) and a per-step copy of the weights as bf16 — rounding an operand when it is stored instead of
+     * every time a tile of it is staged: identical products, half the operand bytes.  A bf16 operand needs its
+     * contiguous extent (K if k-contiguous, else its M / N), its other stride and its batch strides to be
+     * multiples of 8 elements and a 16-byte aligned base (CALM_E_LAYOUT otherwise).  C_pre has C's type.
+     * Split / batch-reduced outputs (fp32 atomics or workspace) must be fp32. */
+    int32_t      a_type, b_type, c_type, aux_type, r_type;
+    int32_t      reserved_;
 } calm_gemm_args;
 #define CALM_GEMM_MAX_GROUP 4
 
@@ -118,12 +129,14 @@ int64_t calm_gemm_workspace_bytes(const calm_gemm_args* args);
  * (dw must be zeroed by the caller; accumulated with atomics).  dx_add (nullable, x's layout): gradient arriving
  * through the skip connection that bypasses the norm (x feeds LN and the block's residual add, Vi_Tools:209-211,
  * 309-315), summed into dx here instead of by a separate elementwise pass.
+ * y_type / dy_type (CALM_ST_*, ABI v4): the normalised output and the gradient arriving for it may be bf16 tensors
+ * (bf16 pipeline: the output only feeds GEMMs; statistics, x and dx stay fp32).
  * ------------------------------------------------------------------------------------- */
-int calm_layernorm_fwd(const float* x, const float* w, float* y, float* mean, float* rstd,
-                       int64_t rows, int32_t D, float eps, void* stream);
-int calm_layernorm_bwd(const float* dy, const float* x, const float* w, const float* mean,
+int calm_layernorm_fwd(const float* x, const float* w, void* y, float* mean, float* rstd,
+                       int64_t rows, int32_t D, float eps, int32_t y_type, void* stream);
+int calm_layernorm_bwd(const void* dy, const float* x, const float* w, const float* mean,
                        const float* rstd, float* dx, float* dw, const float* dx_add, int64_t rows, int32_t D,
-                       void* stream);
+                       int32_t dy_type, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Learned-frequency NeoX RoPE + head assembly (Vi_Tools:80-95 applied at 275-285).
@@ -224,6 +237,22 @@ typedef struct calm_sn_plan_info {
 int calm_sn_plan(const calm_sn_layer* layers, int32_t n, void* blob_host, calm_sn_plan_info* info);
 int calm_sn_power_iter(const void* plan_dev, const calm_sn_plan_info* info, int32_t training,
                        float eps, float* scratch, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * bf16 copies of many fp32 tensors in ONE launch (ABI v4): the bf16 pipeline refreshes the bf16 copy of every weight
+ * once per forward (W_orig itself, not W_orig/sigma: the GEMM epilogues keep dividing by sigma in fp32), next to the
+ * power iteration.  entries_dev: table in device memory; work items are chunks of calm_cast_chunk_elems() consecutive
+ * elements of one entry: chunk_entry_dev[k] = entry of chunk k, entry.chunk0 = its first chunk.  Round to nearest even
+ * (what autocast's weight cast does, torch `.to(bfloat16)`).
+ * ------------------------------------------------------------------------------------- */
+typedef struct calm_cast_entry {
+    const float* src;
+    void*        dst;          /* bf16[numel] */
+    int64_t      numel;
+    int32_t      chunk0, reserved;
+} calm_cast_entry;
+int32_t calm_cast_chunk_elems(void);
+int calm_cast_bf16(const calm_cast_entry* entries_dev, const int32_t* chunk_entry_dev, int32_t n_chunks, void* stream);
 
 /* Weight gradient through W = W_orig / sigma (and an optional LayerScale on the output):
  *   d_ls[c]  = sum_k G[c,k] * W_orig[c,k] / sigma            (only if ls != NULL; written)
@@ -328,13 +357,14 @@ int calm_cnn_residual_bwd(const float* dy, const float* x, const float* w0, cons
  * add          : out = a + b                         (residual / U-net skips, Vi_Tools:309,315,403,513-522)
  * gelu_bwd     : dz = dy * gelu'(z)                  (where it is not fused into a GEMM epilogue)
  * colsum       : out[n] += sum_m x[m,n]              (bias gradients; caller zeroes)
- * row_scale    : out[r,c] = x[r,c] * s[r]            (ls-scaled weight for the dgrad of out_proj/mlp.3)
+ * row_scale    : out[r,c] = x[r,c] * s[r]            (ls-scaled weight for the dgrad of out_proj/mlp.3; fp32 or bf16 out)
  * mean_seq     : y[b,d] = mean_s x[b,s,d]            (AdaptiveAvgPool1d, CALM_ViT_V2.py:74-75) and bwd
  * ------------------------------------------------------------------------------------- */
 int calm_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 int calm_gelu_bwd(const float* dy, const float* z, float* dz, int64_t n, void* stream);
 int calm_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* stream);
-int calm_row_scale(const float* x, const float* s, float* out, int32_t rows, int32_t cols, void* stream);
+int calm_row_scale(const float* x, const float* s, void* out, int32_t rows, int32_t cols, int32_t out_type /* CALM_ST_* */,
+                   void* stream);
 int calm_mean_seq_fwd(const float* x, float* y, int32_t B, int32_t S, int32_t D, void* stream);
 int calm_mean_seq_bwd(const float* dy, float* dx, int32_t B, int32_t S, int32_t D, void* stream);
 

@@ -36,7 +36,7 @@ class EmulatedBackend:
     @staticmethod
     def precision():
         import calm_vit_dte_amd as calm
-        return calm.backend.get_matmul_precision()
+        return calm.backend.effective_precision()
 
     def gemm(self, A, B, Cout, M, N, K, a, b, c, batch=(1, 1), alpha=1.0, inv_scale=None, bias=None,
              col_scale=None, residual=None, r=(0, 0, 0), C_pre=None, aux=None, act=ACT_NONE,
@@ -73,9 +73,12 @@ class EmulatedBackend:
             Cv.copy_(Cv + z if accumulate else z)
             return
         b0, b1 = batch
-        Av = _view(A, (b0, b1, M, K), (a[2], a[3], a[0], a[1]))
-        Bv = _view(B, (b0, b1, N, K), (b[2], b[3], b[0], b[1]))
+        # bf16 tensors (ABI v4 storage types): exact in fp32; an output tensor of type bf16 is rounded when stored
+        Av = _view(A, (b0, b1, M, K), (a[2], a[3], a[0], a[1])).float()
+        Bv = _view(B, (b0, b1, N, K), (b[2], b[3], b[0], b[1])).float()
         prec = self.precision()
+        if any(t is not None and t.dtype == torch.bfloat16 for t in (A, B, Cout, aux, residual)):
+            assert prec == "bf16", "bf16 tensors are accepted by the bf16 matrix pipe only"
         if prec == "bf16":                                  # operands rounded to bf16, fp32 accumulate
             Av, Bv = Av.bfloat16().float(), Bv.bfloat16().float()
             acc = torch.matmul(Av, Bv.transpose(-1, -2))
@@ -103,13 +106,13 @@ class EmulatedBackend:
         if act == ACT_GELU:
             z = _gelu(z)
         elif act == ACT_GELU_BWD:
-            z = z * _gelu_grad(_view(aux, (b0, b1, M, N), (c[1], c[2], c[0], 1)))
+            z = z * _gelu_grad(_view(aux, (b0, b1, M, N), (c[1], c[2], c[0], 1)).float())
         if col_scale is not None:
             z = z * col_scale
         if residual is not None:
-            z = z + _view(residual, (b0, b1, M, N), (r[1], r[2], r[0], 1))
+            z = z + _view(residual, (b0, b1, M, N), (r[1], r[2], r[0], 1)).float()
         if accumulate:
-            z = z + Cv
+            z = z + Cv.float()
         Cv.copy_(z)
 
     def collate_mix(self, img_u8, flip, out, mode, lam, box, mean, std):
@@ -165,6 +168,16 @@ class EmulatedBackend:
             v.mul_(b2).addcmul_(g, g, value=1 - b2)
             p.addcdiv_(m, (v.sqrt() / (bc2 ** 0.5)).add_(eps), value=-lr / bc1)
 
+    def cast_plan(self, pairs):
+        p = EmuPlan([])
+        p.pairs = pairs
+        p.key = tuple(t.data_ptr() for pr in pairs for t in pr)
+        return p
+
+    def cast_run(self, plan):
+        for src, dst in plan.pairs:
+            dst.copy_(src)                                   # fp32 -> bf16, round to nearest even
+
     def layernorm_fwd(self, x, w, y, mean, rstd, rows, D, eps):
         x2 = x.reshape(rows, D)
         mu = x2.mean(dim=1)
@@ -175,7 +188,7 @@ class EmulatedBackend:
         rstd.copy_(rs)
 
     def layernorm_bwd(self, dy, x, w, mean, rstd, dx, dw, rows, D, dx_add=None):
-        x2, g2 = x.reshape(rows, D), dy.reshape(rows, D)
+        x2, g2 = x.reshape(rows, D), dy.reshape(rows, D).float()
         xh = (x2 - mean[:, None]) * rstd[:, None]
         g = g2 * w
         c1 = g.mean(dim=1, keepdim=True)

@@ -284,3 +284,81 @@ def test_grouped_projection_gemm_on_the_bf16_pipe(prec, tol, M, D):
     for g in range(n):
         assert rel_err(y_hip[g], y_ref[g]) < tol
     assert rel_err(dx_hip, dx_ref) < tol
+
+
+# ---- bf16 tensors in HBM (ABI v4 storage types): activations / weight copies of the bf16 pipeline ---------------------
+TYPED_CASES = [
+    # M, N, K, batch, a_kcontig, b_kcontig   (bf16 operands: contiguous extent and strides are multiples of 8)
+    (256, 384, 128, (1, 1), True, True),
+    (200, 136, 72, (2, 3), True, False),
+    (136, 264, 40, (3, 1), False, True),
+    (128, 96, 256, (1, 2), False, False),
+    (672, 672, 1024, (1, 1), False, False),      # weight-gradient layout (split over k: fp32 output)
+    (224, 224, 112, (2, 6), True, True),
+    (40, 24, 48, (1, 1), True, True),
+    (16392, 1000, 200, (1, 1), True, True),      # wide 256x128 tile, ragged M and N
+    (8200, 1928, 96, (1, 1), False, False),
+    (8200, 2064, 40, (1, 1), False, True),
+]
+
+
+@pytest.mark.parametrize("M,N,K,batch,akc,bkc", TYPED_CASES)
+@pytest.mark.parametrize("ta,tb", [("bf16", "bf16"), ("bf16", "f32"), ("f32", "bf16")])
+@pytest.mark.parametrize("epi", ["plain", "full_bf16_out"])
+def test_gemm_with_bf16_tensors_in_hbm(M, N, K, batch, akc, bkc, ta, tb, epi):
+    """calm_gemm on operands that are already bf16 in HBM (no conversion while staging, 8 elements per 16-byte vector)
+    and with bf16 outputs / epilogue operands, against the emulation: bf16 inputs are exact in fp32, fp32 inputs are
+    rounded while staged, the output is rounded once when stored."""
+    hip, emu = calm.backend.get_backend(), EmulatedBackend()
+    b0, b1 = batch
+    dt = {"bf16": torch.bfloat16, "f32": torch.float32}
+    A, a = _operand(M, K, batch, akc, 1)
+    B, b = _operand(N, K, batch, bkc, 2)
+    A, B = A.to(dt[ta]), B.to(dt[tb])
+    c = (N, b1 * M * N, M * N)
+    calm.backend.set_matmul_precision("bf16")
+    if epi == "plain":
+        kw, cdt, tol = {}, torch.float32, 2e-4
+    else:
+        kw = dict(alpha=0.5, inv_scale=torch.tensor([1.3]), bias=rnd(N, seed=3), col_scale=rnd(N, seed=4),
+                  residual=rnd(b0, b1, M, N, seed=5), r=c, act=2, aux=rnd(b0, b1, M, N, seed=6).bfloat16(), split_k=1)
+        cdt, tol = torch.bfloat16, 6e-3                     # one bf16 ulp of the largest output
+    kw_hip = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
+    C_ref = torch.zeros(b0, b1, M, N, dtype=cdt)
+    C_hip = torch.full((b0, b1, M, N), 7.0, dtype=cdt).cuda()
+    emu.gemm(A, B, C_ref, M, N, K, a, b, c, batch=batch, **kw)
+    hip.gemm(A.cuda(), B.cuda(), C_hip, M, N, K, a, b, c, batch=batch, **kw_hip)
+    assert rel_err(C_hip.float(), C_ref.float()) < tol
+    if cdt == torch.bfloat16:                               # rounding-flip free elements agree exactly: most of them
+        same = (C_hip.cpu() == C_ref).float().mean()
+        assert same > 0.97, float(same)
+
+
+def test_gemm_mlp_pattern_with_bf16_hidden_and_preactivation():
+    """The MLP's first GEMM in the bf16 pipeline: bf16 LayerNorm output x bf16 weight copy -> bf16 GELU output and
+    bf16 pre-activation (C and C_pre), bias in fp32."""
+    hip, emu = calm.backend.get_backend(), EmulatedBackend()
+    M, K, N = 3000, 672, 1344
+    calm.backend.set_matmul_precision("bf16")
+    x, w, bias, sg = rnd(M, K, seed=1).bfloat16(), (rnd(N, K, seed=2) * 0.05).bfloat16(), rnd(N, seed=3), torch.tensor([0.7])
+    outs = []
+    for be, dev in ((emu, "cpu"), (hip, "cuda")):
+        C = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        P = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+        be.gemm(x.to(dev), w.to(dev), C, M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), inv_scale=sg.to(dev),
+                bias=bias.to(dev), act=1, C_pre=P, split_k=1)
+        outs.append((C.float().cpu(), P.float().cpu()))
+    assert rel_err(outs[1][0], outs[0][0]) < 6e-3 and rel_err(outs[1][1], outs[0][1]) < 6e-3
+    assert (outs[1][0] == outs[0][0]).float().mean() > 0.97
+
+
+def test_gemm_rejects_bf16_tensors_it_cannot_stage():
+    hip = calm.backend.get_backend()
+    calm.backend.set_matmul_precision("bf16")
+    A, B, C = rnd(64, 36).bfloat16().cuda(), rnd(64, 36).cuda(), torch.zeros(64, 64).cuda()
+    with pytest.raises(RuntimeError):                       # K = 36 is not a multiple of 8: no 16-byte bf16 vectors
+        hip.gemm(A, B, C, 64, 64, 36, (36, 1, 0, 0), (36, 1, 0, 0), (64, 0, 0))
+    calm.backend.set_matmul_precision("fp32")
+    A = rnd(64, 64).bfloat16().cuda()
+    with pytest.raises(RuntimeError):                       # bf16 tensors need the bf16 matrix pipe
+        hip.gemm(A, rnd(64, 64).cuda(), C, 64, 64, 64, (64, 1, 0, 0), (64, 1, 0, 0), (64, 0, 0))
