@@ -81,6 +81,7 @@ SIGNATURES = {
     "calm_layernorm_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "calm_cast_chunk_elems": (_i32, []),
     "calm_cast_bf16": (_i32, [_p, _p, _i32, _p]),
+    "calm_cast_bf16_one": (_i32, [_p, _p, _i64, _p]),
     "calm_rope_fwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "calm_rope_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
     "calm_softmax_fwd": (_i32, [_p, _i64, _i32, _p]),

@@ -300,6 +300,10 @@ class HipBackend:
         plan.n_chunks = len(chunk_entry)
         return plan
 
+    def cast_bf16(self, src, dst):
+        _lib.check(self.lib.calm_cast_bf16_one(_ptr(src), _ptr(dst, bf16_ok=True), src.numel(), _stream()),
+                   "calm_cast_bf16_one")
+
     def cast_run(self, plan):
         _lib.check(self.lib.calm_cast_bf16(plan.blob_dev.data_ptr(), plan.scratch.data_ptr(), plan.n_chunks, _stream()),
                    "calm_cast_bf16")

@@ -162,11 +162,34 @@ __global__ __launch_bounds__(NT) void cast_bf16_kernel(const calm_cast_entry* __
     }
 }
 
+typedef __bf16 bf16x8c __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(NT) void cast_one_kernel(const float* __restrict__ src, __bf16* __restrict__ dst, long n8, long n) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n8; i += (long)gridDim.x * NT) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(src)[2 * i], b = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+        reinterpret_cast<bf16x8c*>(dst)[i] = (bf16x8c){(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3],
+                                                       (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+    }
+    for (long i = 8 * n8 + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) dst[i] = (__bf16)src[i];
+}
+
 }  // namespace
 
 extern "C" {
 
 int32_t calm_cast_chunk_elems(void) { return CAST_CHUNK; }
+
+int calm_cast_bf16_one(const float* src, void* dst, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0) return CALM_E_INVAL;
+    const bool vec = aligned16(src) && aligned16(dst);
+    const long n8 = vec ? n / 8 : 0;
+    long g = (n / 8 + NT - 1) / NT;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    hipLaunchKernelGGL(cast_one_kernel, dim3((int)g), dim3(NT), 0, as_stream(stream), src, reinterpret_cast<__bf16*>(dst), n8,
+                       (long)n);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
 
 int calm_cast_bf16(const calm_cast_entry* entries_dev, const int32_t* chunk_entry_dev, int32_t n_chunks, void* stream) {
     if (!entries_dev || !chunk_entry_dev || n_chunks <= 0) return CALM_E_INVAL;

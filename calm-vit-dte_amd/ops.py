@@ -138,6 +138,20 @@ def _sn_wbwd(be, G, w, u, v, sigma, ls=None, defer=False):
     return dW, d_ls
 
 
+CAST_GRADS = os.environ.get("CALM_CAST_GRADS", "1") != "0"      # A/B switch
+
+
+def _gop(be, g2):
+    """GEMM operand for a fp32 gradient [M, N] that the backward is about to read TWICE (weight gradient and input
+    gradient): in the bf16 pipeline a bf16 copy made by one pass (6 bytes per element) — each of the two GEMMs then
+    stages 2 bytes per element without converting.  Same products as rounding while staging."""
+    if CAST_GRADS and bf16_pipeline() and g2.dtype == torch.float32 and g2.shape[-1] % 8 == 0 and g2.numel() >= (1 << 20):
+        g16 = torch.empty(g2.shape, dtype=torch.bfloat16, device=g2.device)
+        be.cast_bf16(g2, g16)
+        return g16
+    return g2
+
+
 def _colsum(be, x2):
     if x2.dtype != torch.float32:
         x2 = x2.float()                     # bias gradients of bf16 tensors: not on the model's path (its MLPs have no bias)
@@ -258,8 +272,9 @@ class SNLinearFn(Function):
             be.gelu_bwd(dy2, pre.view(-1, N), dz, dy2.numel())
         else:
             dz = dy2
+        dzg = _gop(be, dz) if ctx.needs_input_grad[0] else dz
         G = _zeros_big(w.shape, w)
-        _lin_wgrad(be, dz, x2, G)
+        _lin_wgrad(be, dzg, x2, G)
         dW, d_ls = _sn_wbwd(be, G, w, u, v, sigma, ls, defer=ctx.defer)
         dx = None
         if ctx.needs_input_grad[0]:
@@ -269,7 +284,7 @@ class SNLinearFn(Function):
                 be.row_scale(w, ls, wl, N, K)
             else:
                 wl = ctx.wop
-            _lin_dgrad(be, dz, wl, sigma, dx)
+            _lin_dgrad(be, dzg, wl, sigma, dx)
             dx = dx.view(ctx.xshape)
         db = _colsum(be, dz) if ctx.has_bias else None
         dres = dy if ctx.has_res else None
@@ -317,6 +332,8 @@ class SNLinearGroupFn(Function):
         N, K = ws[0].shape
         M = x2.shape[0]
         dy2 = [_c(d).reshape(-1, N) for d in dys]
+        if ctx.needs_input_grad[0]:
+            dy2 = [_gop(be, d) for d in dy2]             # each is read by the weight-gradient and the input-gradient launch
         # weight gradients G_g = dy_g^T x: one grouped launch, every group split over its own k-slices
         Gs = [_zeros_big(w.shape, w) for w in ws]
         be.gemm(dy2, x2, Gs, N, K, M, (1, N, 0, 0), (1, K, 0, 0), (K, 0, 0), batch=(n, 1), accumulate=True)
@@ -370,8 +387,9 @@ class MlpFn(Function):
         N, Hd = w2.shape
         K = w1.shape[1]
         do2 = _c(dout).reshape(-1, N)
+        do2g = _gop(be, do2)
         G2 = _zeros_big(w2.shape, w2)
-        _lin_wgrad(be, do2, hg, G2)
+        _lin_wgrad(be, do2g, hg, G2)
         dW2, d_ls = _sn_wbwd(be, G2, w2, u2, v2, s2, ls, defer=ctx.defer[1])
         db2 = _colsum(be, do2) if ctx.has_b2 else None
         wop1, wop2 = ctx.wops
@@ -381,7 +399,7 @@ class MlpFn(Function):
         else:
             w2l = wop2
         dhp = torch.empty_like(hp)
-        _lin_dgrad(be, do2, w2l, s2, dhp, act=ACT_GELU_BWD, aux=hp)
+        _lin_dgrad(be, do2g, w2l, s2, dhp, act=ACT_GELU_BWD, aux=hp)
         G1 = _zeros_big(w1.shape, w1)
         _lin_wgrad(be, dhp, x2, G1)
         dW1, _ = _sn_wbwd(be, G1, w1, u1, v1, s1, defer=ctx.defer[0])

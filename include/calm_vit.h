@@ -253,6 +253,8 @@ typedef struct calm_cast_entry {
 } calm_cast_entry;
 int32_t calm_cast_chunk_elems(void);
 int calm_cast_bf16(const calm_cast_entry* entries_dev, const int32_t* chunk_entry_dev, int32_t n_chunks, void* stream);
+/* one tensor: dst[i] = bf16(src[i]) — the fp32 residual-stream gradient that two backward GEMMs are about to read */
+int calm_cast_bf16_one(const float* src, void* dst, int64_t n, void* stream);
 
 /* Weight gradient through W = W_orig / sigma (and an optional LayerScale on the output):
  *   d_ls[c]  = sum_k G[c,k] * W_orig[c,k] / sigma            (only if ls != NULL; written)

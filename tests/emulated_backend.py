@@ -174,6 +174,9 @@ class EmulatedBackend:
         p.key = tuple(t.data_ptr() for pr in pairs for t in pr)
         return p
 
+    def cast_bf16(self, src, dst):
+        dst.copy_(src)
+
     def cast_run(self, plan):
         for src, dst in plan.pairs:
             dst.copy_(src)                                   # fp32 -> bf16, round to nearest even
