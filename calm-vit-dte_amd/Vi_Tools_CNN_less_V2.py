@@ -125,7 +125,7 @@ class RoPE(torch.nn.Module):
     def forward(self, x):
         B, H, S, d = x.shape
         xt = x.transpose(1, 2).reshape(B, S, H * d)
-        y = ops.RopeFn.apply(None, xt, self.inv_freq, H)
+        y = ops.RopeFn.apply(None, xt, self.inv_freq, H, False)
         return y.view(B, S, H, d).transpose(1, 2)
 
 
@@ -246,20 +246,20 @@ class VMLA_Block(torch.nn.Module):
         with sn_scope(self):
             return self._forward(input_q, input_kv, state_manager)
 
-    def _project_qkv(self, qz, kz, vz):
+    def _project_qkv(self, qz, kz, vz, out16=False):
         """q_proj / k_proj / v_proj (Vi_Tools:265-267).  Projections that read the SAME tensor — all three in a plain
         self-attention block, k and v whenever the key and value inputs coincide — run as one grouped launch."""
         pq, pk, pv = self.q_proj, self.k_proj, self.v_proj
         pack = lambda *ps: [t for p_ in ps for t in (p_.weight_orig, p_.weight_u, p_.weight_v, p_.sigma())]
         same_shape = pq.weight_orig.shape == pk.weight_orig.shape == pv.weight_orig.shape
         if any(p_.bias is not None for p_ in (pq, pk, pv)) or not same_shape or not ops.GROUP_PROJECTIONS:
-            return pq(qz), pk(kz), pv(vz)
+            return pq(qz, out16=out16), pk(kz, out16=out16), pv(vz, out16=out16)
         if qz is kz and kz is vz:
-            return ops.SNLinearGroupFn.apply(qz, *pack(pq, pk, pv))
+            return ops.SNLinearGroupFn.apply(qz, out16, *pack(pq, pk, pv))
         if kz is vz:
-            k, v = ops.SNLinearGroupFn.apply(kz, *pack(pk, pv))
-            return pq(qz), k, v
-        return pq(qz), pk(kz), pv(vz)
+            k, v = ops.SNLinearGroupFn.apply(kz, out16, *pack(pk, pv))
+            return pq(qz, out16=out16), k, v
+        return pq(qz, out16=out16), pk(kz, out16=out16), pv(vz, out16=out16)
 
     def _forward(self, input_q, input_kv, state_manager):
         H = self.heads
@@ -289,17 +289,20 @@ class VMLA_Block(torch.nn.Module):
                 vz = self._seq(self.t_vz_upsample, vz)
                 qr = self._seq(self.t_qr_proj, qr)
                 kr = self._seq(self.t_kr_proj, kr)
-        qz, kz, v = self._project_qkv(qz, kz, vz)                        # 265-267
+        # bf16 pipeline: q, k, v are bf16 from the projections through RoPE into the bf16 attention kernels
+        a16 = qz.shape[1] == kz.shape[1] and ops.use_attention16(qz.shape[1], H, self.head_dim)
+        qz, kz, v = self._project_qkv(qz, kz, vz, out16=a16)             # 265-267
         if self.reduce:                                                  # 275-281 decoupled RoPE
-            qr = self.qr_proj(qr)
-            kr = self.kr_proj(kr)
-            q = ops.RopeFn.apply(qz, qr, self.rope_q.inv_freq, H)
-            k = ops.RopeFn.apply(kz, kr, self.rope_k.inv_freq, H)
+            qr = self.qr_proj(qr, out16=a16)
+            kr = self.kr_proj(kr, out16=a16)
+            q = ops.RopeFn.apply(qz, qr, self.rope_q.inv_freq, H, a16)
+            k = ops.RopeFn.apply(kz, kr, self.rope_k.inv_freq, H, a16)
         else:                                                            # 283-285
-            q = ops.RopeFn.apply(None, qz, self.rope_q.inv_freq, H)
-            k = ops.RopeFn.apply(None, kz, self.rope_k.inv_freq, H)
+            q = ops.RopeFn.apply(None, qz, self.rope_q.inv_freq, H, a16)
+            k = ops.RopeFn.apply(None, kz, self.rope_k.inv_freq, H, a16)
         m0, m2 = self.linear_mask[0], self.linear_mask[2]
-        x = ops.LatentMaskAttentionFn.apply(                             # 288-299
+        attention = ops.LatentMaskAttention16Fn if a16 else ops.LatentMaskAttentionFn
+        x = attention.apply(                                             # 288-299
             q, k, v, m0.weight_orig, m0.bias, m2.weight_orig, m2.bias,
             m0.weight_u, m0.weight_v, m0.sigma(), m2.weight_u, m2.weight_v, m2.sigma(), H)
         if residual.shape != (x.shape[0], x.shape[1], self.out_proj.out_features):   # 302-308

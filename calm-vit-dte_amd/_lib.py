@@ -82,8 +82,8 @@ SIGNATURES = {
     "calm_cast_chunk_elems": (_i32, []),
     "calm_cast_bf16": (_i32, [_p, _p, _i32, _p]),
     "calm_cast_bf16_one": (_i32, [_p, _p, _i64, _p]),
-    "calm_rope_fwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
-    "calm_rope_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p]),
+    "calm_rope_fwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "calm_rope_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "calm_softmax_fwd": (_i32, [_p, _i64, _i32, _p]),
     "calm_softmax_bwd": (_i32, [_p, _p, _i64, _i32, _p]),
     "calm_softmax_bwd_heads": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
@@ -92,6 +92,9 @@ SIGNATURES = {
     "calm_attention_fwd": (_i32, [_p] * 15 + [_i32] * 5 + [_p]),
     "calm_attention_bwd_preferred": (_i32, [_i32, _i32, _i32, _i32]),
     "calm_attention_bwd": (_i32, [_p] * 10 + [_i32] * 5 + [_p]),
+    "calm_attention16_supported": (_i32, [_i32, _i32, _i32]),
+    "calm_attention16_fwd": (_i32, [_p] * 16 + [_i32] * 4 + [_p]),
+    "calm_attention16_bwd": (_i32, [_p] * 13 + [_i32] * 4 + [_p]),
     "calm_latent_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _p]),
     "calm_latent_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "calm_sn_plan": (_i32, [C.POINTER(SnLayer), _i32, _p, C.POINTER(SnPlanInfo)]),

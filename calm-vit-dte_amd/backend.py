@@ -66,6 +66,12 @@ def _ptr(t, allow_none=False, bf16_ok=False):
     return t.data_ptr()
 
 
+def _ptr16(t):
+    if t is None or not t.is_cuda or t.dtype != torch.bfloat16 or not t.is_contiguous():
+        raise TypeError("contiguous bf16 CUDA tensor expected")
+    return t.data_ptr()
+
+
 def _st(t):
     """CALM_ST_* storage type of a tensor argument (None -> fp32)."""
     return _lib.ST_BF16 if t is not None and t.dtype == torch.bfloat16 else _lib.ST_F32
@@ -310,12 +316,16 @@ class HipBackend:
 
     # ---- RoPE -------------------------------------------------------------------------
     def rope_fwd(self, content, xr, inv_freq, table, out, B, S, H, dc, dr):
-        _lib.check(self.lib.calm_rope_fwd(_ptr(content, True), _ptr(xr), _ptr(inv_freq), _ptr(table), _ptr(out),
-                                          B, S, H, dc, dr, _stream()), "calm_rope_fwd")
+        """content / xr / out: fp32 or bf16 tensors, independently."""
+        _lib.check(self.lib.calm_rope_fwd(_ptr(content, True, bf16_ok=True), _ptr(xr, bf16_ok=True), _ptr(inv_freq),
+                                          _ptr(table), _ptr(out, bf16_ok=True), B, S, H, dc, dr, _st(content), _st(xr),
+                                          _st(out), _stream()), "calm_rope_fwd")
 
     def rope_bwd(self, d_out, xr, table, d_content, d_xr, d_inv_freq, B, S, H, dc, dr):
-        _lib.check(self.lib.calm_rope_bwd(_ptr(d_out), _ptr(xr), _ptr(table), _ptr(d_content, True), _ptr(d_xr),
-                                          _ptr(d_inv_freq), B, S, H, dc, dr, _stream()), "calm_rope_bwd")
+        _lib.check(self.lib.calm_rope_bwd(_ptr(d_out, bf16_ok=True), _ptr(xr, bf16_ok=True), _ptr(table),
+                                          _ptr(d_content, True, bf16_ok=True), _ptr(d_xr, bf16_ok=True), _ptr(d_inv_freq),
+                                          B, S, H, dc, dr, _st(d_out), _st(xr), _st(d_content), _st(d_xr), _stream()),
+                   "calm_rope_bwd")
 
     # ---- softmax ----------------------------------------------------------------------
     def softmax_fwd(self, x, rows, cols):
@@ -347,6 +357,22 @@ class HipBackend:
         _lib.check(self.lib.calm_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(dout), _ptr(P), _ptr(dS), _ptr(dq),
                                                _ptr(dk), _ptr(dv), _ptr(dM), B, Sq, Skv, H, hd, _stream()),
                    "calm_attention_bwd")
+
+    # ---- the same attention on the bf16 matrix pipe (bf16 pipeline) ----------------------
+    def attn16_supported(self, S, H, hd):
+        return bool(self.lib.calm_attention16_supported(S, H, hd))
+
+    def attn16_fwd(self, q, k, v, w1, b1, s1, w2, b2, s2, out, R, hp, hg, Mk, MkT, lse, B, S, H, hd):
+        h = lambda t: _ptr16(t)
+        _lib.check(self.lib.calm_attention16_fwd(h(q), h(k), h(v), h(w1), _ptr(b1), _ptr(s1), h(w2), _ptr(b2), _ptr(s2),
+                                                 h(out), h(R), h(hp), h(hg), h(Mk), h(MkT), _ptr(lse), B, S, H, hd,
+                                                 _stream()), "calm_attention16_fwd")
+
+    def attn16_bwd(self, q, k, v, out, dout, Mk, MkT, lse, delta, dq, dk, dv, dM, B, S, H, hd):
+        h = lambda t: _ptr16(t)
+        _lib.check(self.lib.calm_attention16_bwd(h(q), h(k), h(v), h(out), h(dout), h(Mk), h(MkT), _ptr(lse), _ptr(delta),
+                                                 h(dq), h(dk), h(dv), h(dM), B, S, H, hd, _stream()),
+                   "calm_attention16_bwd")
 
     # ---- latent -----------------------------------------------------------------------
     def latent_fwd(self, mv, noise, z, std, kl_sum, rows, mvh):

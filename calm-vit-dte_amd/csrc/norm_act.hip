@@ -243,37 +243,48 @@ __global__ void rope_table_kernel(const float* __restrict__ inv_freq, float* __r
     table[S * half + i] = sinf(ang);
 }
 
-__global__ __launch_bounds__(NT) void rope_fwd_kernel(const float* __restrict__ content, const float* __restrict__ xr,
-                                                      const float* __restrict__ table, float* __restrict__ out,
-                                                      long nrows, int S, int H, int dc, int dr) {
+// element access by storage type (CALM_ST_*): the bf16 pipeline keeps projection outputs / attention operands as bf16
+__device__ __forceinline__ float ldt(const void* p, long i, int type) {
+    return type == CALM_ST_BF16 ? (float)reinterpret_cast<const __bf16*>(p)[i] : reinterpret_cast<const float*>(p)[i];
+}
+__device__ __forceinline__ void stt(void* p, long i, float v, int type) {
+    if (type == CALM_ST_BF16) reinterpret_cast<__bf16*>(p)[i] = (__bf16)v;
+    else reinterpret_cast<float*>(p)[i] = v;
+}
+
+__global__ __launch_bounds__(NT) void rope_fwd_kernel(const void* __restrict__ content, const void* __restrict__ xr,
+                                                      const float* __restrict__ table, void* __restrict__ out,
+                                                      long nrows, int S, int H, int dc, int dr, int content_type,
+                                                      int xr_type, int out_type) {
     const int half = dr >> 1;
-    const int wd = dc + half;                   // work items per (b,s,h) row
+    const int wd = dc + half;                 // work items per row: dc copies + half rotations
     const long total = nrows * wd;
     const float* cosT = table;
     const float* sinT = table + (long)S * half;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const long row = i / wd;
         const int j = (int)(i - row * wd);
-        float* o = out + row * (dc + dr);
+        const long o = row * (dc + dr);
         if (j < dc) {
-            o[j] = content[row * dc + j];
+            stt(out, o + j, ldt(content, row * dc + j, content_type), out_type);
         } else {
             const int jj = j - dc;
             const int s = (int)((row / H) % S);
             const float c = cosT[s * half + jj], sn = sinT[s * half + jj];
-            const float x1 = xr[row * dr + jj], x2 = xr[row * dr + jj + half];
-            o[dc + jj] = x1 * c - x2 * sn;
-            o[dc + jj + half] = x2 * c + x1 * sn;
+            const float x1 = ldt(xr, row * dr + jj, xr_type), x2 = ldt(xr, row * dr + jj + half, xr_type);
+            stt(out, o + dc + jj, x1 * c - x2 * sn, out_type);
+            stt(out, o + dc + jj + half, x2 * c + x1 * sn, out_type);
         }
     }
 }
 
 constexpr int ROPE_MAX_HALF = 256;
 
-__global__ __launch_bounds__(NT) void rope_bwd_kernel(const float* __restrict__ d_out, const float* __restrict__ xr,
-                                                      const float* __restrict__ table, float* __restrict__ d_content,
-                                                      float* __restrict__ d_xr, float* __restrict__ d_inv_freq,
-                                                      long nrows, int S, int H, int dc, int dr) {
+__global__ __launch_bounds__(NT) void rope_bwd_kernel(const void* __restrict__ d_out, const void* __restrict__ xr,
+                                                      const float* __restrict__ table, void* __restrict__ d_content,
+                                                      void* __restrict__ d_xr, float* __restrict__ d_inv_freq,
+                                                      long nrows, int S, int H, int dc, int dr, int dout_type,
+                                                      int xr_type, int dcontent_type, int dxr_type) {
     __shared__ float facc[ROPE_MAX_HALF];
     const int half = dr >> 1;
     for (int j = threadIdx.x; j < half; j += NT) facc[j] = 0.f;
@@ -285,17 +296,17 @@ __global__ __launch_bounds__(NT) void rope_bwd_kernel(const float* __restrict__ 
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
         const long row = i / wd;
         const int j = (int)(i - row * wd);
-        const float* g = d_out + row * (dc + dr);
+        const long go = row * (dc + dr);
         if (j < dc) {
-            d_content[row * dc + j] = g[j];
+            stt(d_content, row * dc + j, ldt(d_out, go + j, dout_type), dcontent_type);
         } else {
             const int jj = j - dc;
             const int s = (int)((row / H) % S);
             const float c = cosT[s * half + jj], sn = sinT[s * half + jj];
-            const float g1 = g[dc + jj], g2 = g[dc + jj + half];
-            const float x1 = xr[row * dr + jj], x2 = xr[row * dr + jj + half];
-            d_xr[row * dr + jj] = g1 * c + g2 * sn;
-            d_xr[row * dr + jj + half] = g2 * c - g1 * sn;
+            const float g1 = ldt(d_out, go + dc + jj, dout_type), g2 = ldt(d_out, go + dc + jj + half, dout_type);
+            const float x1 = ldt(xr, row * dr + jj, xr_type), x2 = ldt(xr, row * dr + jj + half, xr_type);
+            stt(d_xr, row * dr + jj, g1 * c + g2 * sn, dxr_type);
+            stt(d_xr, row * dr + jj + half, g2 * c - g1 * sn, dxr_type);
             // d/d(angle): y1 = x1 c - x2 s, y2 = x2 c + x1 s ; angle = s * inv_freq[jj]
             const float dang = g1 * (-x1 * sn - x2 * c) + g2 * (-x2 * sn + x1 * c);
             atomicAdd(&facc[jj], dang * (float)s);
@@ -649,34 +660,40 @@ int calm_layernorm_bwd(const void* dy, const float* x, const float* w, const flo
     return 0;
 }
 
-int calm_rope_fwd(const float* content, const float* xr, const float* inv_freq, float* table, float* out, int32_t B,
-                  int32_t S, int32_t H, int32_t dc, int32_t dr, void* stream) {
+static bool st_ok(int t) { return t == CALM_ST_F32 || t == CALM_ST_BF16; }
+
+int calm_rope_fwd(const void* content, const void* xr, const float* inv_freq, float* table, void* out, int32_t B,
+                  int32_t S, int32_t H, int32_t dc, int32_t dr, int32_t content_type, int32_t xr_type, int32_t out_type,
+                  void* stream) {
     if (!xr || !inv_freq || !table || !out || B <= 0 || S <= 0 || H <= 0 || dc < 0 || dr <= 0 || (dr & 1))
         return CALM_E_INVAL;
     if (dc > 0 && !content) return CALM_E_INVAL;
+    if (!st_ok(content_type) || !st_ok(xr_type) || !st_ok(out_type)) return CALM_E_INVAL;
     const int half = dr / 2;
     hipLaunchKernelGGL(rope_table_kernel, dim3((S * half + 255) / 256), dim3(256), 0, as_stream(stream), inv_freq,
                        table, S, half);
     CALM_LAUNCH_CHECK();
     const long nrows = (long)B * S * H;
     hipLaunchKernelGGL(rope_fwd_kernel, dim3(grid_for(nrows * (dc + half), NT)), dim3(NT), 0, as_stream(stream),
-                       content, xr, table, out, nrows, S, H, dc, dr);
+                       content, xr, table, out, nrows, S, H, dc, dr, content_type, xr_type, out_type);
     CALM_LAUNCH_CHECK();
     return 0;
 }
 
-int calm_rope_bwd(const float* d_out, const float* xr, const float* table, float* d_content, float* d_xr,
-                  float* d_inv_freq, int32_t B, int32_t S, int32_t H, int32_t dc, int32_t dr, void* stream) {
+int calm_rope_bwd(const void* d_out, const void* xr, const float* table, void* d_content, void* d_xr,
+                  float* d_inv_freq, int32_t B, int32_t S, int32_t H, int32_t dc, int32_t dr, int32_t dout_type,
+                  int32_t xr_type, int32_t dcontent_type, int32_t dxr_type, void* stream) {
     if (!d_out || !xr || !table || !d_xr || !d_inv_freq || B <= 0 || S <= 0 || H <= 0 || dc < 0 || dr <= 0 ||
         (dr & 1))
         return CALM_E_INVAL;
     if (dc > 0 && !d_content) return CALM_E_INVAL;
+    if (!st_ok(dout_type) || !st_ok(xr_type) || !st_ok(dcontent_type) || !st_ok(dxr_type)) return CALM_E_INVAL;
     if (dr / 2 > ROPE_MAX_HALF) return CALM_E_UNSUPP;
     const long nrows = (long)B * S * H;
     int g = grid_for(nrows * (dc + dr / 2), NT);
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(rope_bwd_kernel, dim3(g), dim3(NT), 0, as_stream(stream), d_out, xr, table, d_content, d_xr,
-                       d_inv_freq, nrows, S, H, dc, dr);
+                       d_inv_freq, nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type, dxr_type);
     CALM_LAUNCH_CHECK();
     return 0;
 }

@@ -238,14 +238,17 @@ class SNLinearFn(Function):
 
     @staticmethod
     @_amp_fwd
-    def forward(ctx, x, w, bias, ls, residual, u, v, sigma, act):
+    def forward(ctx, x, w, bias, ls, residual, u, v, sigma, act, out16=False):
         be = get_backend()
         x = _c(x)
         K = x.shape[-1]
         N = w.shape[0]
         x2 = x.reshape(-1, K)
         wop = _wop(w)
-        out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
+        # out16: the output feeds RoPE / the bf16 attention only (q, k, v projections) -> a bf16 tensor in the bf16 pipeline
+        if out16 and (act != ACT_NONE or ls is not None or residual is not None):
+            raise ValueError("a bf16 projection output takes no activation / LayerScale / residual epilogue")
+        out = torch.empty(x.shape[:-1] + (N,), dtype=act_dtype(N) if out16 else torch.float32, device=x.device)
         pre = torch.empty_like(out) if act == ACT_GELU else None
         res2 = _c(residual).reshape(-1, N) if residual is not None else None
         _lin_fwd(be, x2, wop, sigma, out.view(-1, N), bias=bias, act=act, col_scale=ls, residual=res2,
@@ -288,7 +291,7 @@ class SNLinearFn(Function):
             dx = dx.view(ctx.xshape)
         db = _colsum(be, dz) if ctx.has_bias else None
         dres = dy if ctx.has_res else None
-        return dx, dW, db, d_ls, dres, None, None, None, None
+        return dx, dW, db, d_ls, dres, None, None, None, None, None
 
 
 class SNLinearGroupFn(Function):
@@ -296,11 +299,11 @@ class SNLinearGroupFn(Function):
     activation — q/k/v of a plain self-attention block, k/v of the others (Vi_Tools:265-267) — as ONE grouped launch
     (more tiles per launch: fewer partly filled rounds), and their input gradient dx = sum_g dy_g W_g / sigma_g as one
     pass over the concatenated reduction instead of n GEMMs plus n-1 gradient additions.
-    apply(x, w_0, u_0, v_0, sigma_0, w_1, ...) -> (y_0, ..., y_{n-1})"""
+    apply(x, out16, w_0, u_0, v_0, sigma_0, w_1, ...) -> (y_0, ..., y_{n-1});  out16: bf16 outputs in the bf16 pipeline"""
 
     @staticmethod
     @_amp_fwd
-    def forward(ctx, x, *wuvs):
+    def forward(ctx, x, out16, *wuvs):
         be = get_backend()
         n = len(wuvs) // 4
         ws, sigmas = list(wuvs[0::4]), list(wuvs[3::4])
@@ -311,7 +314,8 @@ class SNLinearGroupFn(Function):
         x2 = x.reshape(-1, K)
         M = x2.shape[0]
         wops = [_wop(w) for w in ws]
-        outs = [torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device) for _ in range(n)]
+        odt = act_dtype(N) if out16 else torch.float32
+        outs = [torch.empty(x.shape[:-1] + (N,), dtype=odt, device=x.device) for _ in range(n)]
         be.gemm(x2, wops, [o.view(-1, N) for o in outs], M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), batch=(n, 1),
                 inv_scale=sigmas, split_k=1)
         ctx.n = n
@@ -346,7 +350,7 @@ class SNLinearGroupFn(Function):
             be.gemm(dy2, ctx.wops, dx, M, K, N, (N, 1, 0, 0), (1, K, 0, 0), (K, 0, 0), batch=(n, 1), inv_scale=sigmas,
                     reduce_batch=True, split_k=1)
             dx = dx.view(ctx.xshape)
-        return (dx, *grads)
+        return (dx, None, *grads)
 
 
 class MlpFn(Function):
@@ -460,7 +464,7 @@ class RopeFn(Function):
 
     @staticmethod
     @_amp_fwd
-    def forward(ctx, content, xr, inv_freq, H):
+    def forward(ctx, content, xr, inv_freq, H, out16=False):
         be = get_backend()
         xr = _c(xr)
         B, S, W = xr.shape
@@ -469,10 +473,12 @@ class RopeFn(Function):
         if content is not None:
             content = _c(content)
             dc = content.shape[-1] // H
-        table = torch.empty(2 * S * (dr // 2), dtype=xr.dtype, device=xr.device)
-        out = torch.empty(B, S, H * (dc + dr), dtype=xr.dtype, device=xr.device)
+        table = torch.empty(2 * S * (dr // 2), dtype=torch.float32, device=xr.device)
+        # out16: q / k for the bf16 attention kernels; the inputs may be fp32 or bf16 projection outputs, independently
+        out = torch.empty(B, S, H * (dc + dr), dtype=torch.bfloat16 if out16 else torch.float32, device=xr.device)
         be.rope_fwd(content, xr, inv_freq, table, out, B, S, H, dc, dr)
         ctx.dims = (B, S, H, dc, dr)
+        ctx.content_dtype = content.dtype if content is not None else None
         ctx.save_for_backward(xr, table)
         return out
 
@@ -484,11 +490,11 @@ class RopeFn(Function):
         xr, table = ctx.saved_tensors
         B, S, H, dc, dr = ctx.dims
         dout = _c(dout)
-        d_xr = torch.empty_like(xr)
-        d_content = torch.empty(B, S, H * dc, dtype=xr.dtype, device=xr.device) if dc > 0 else None
-        d_if = _zeros((dr // 2,), xr)
+        d_xr = torch.empty_like(xr)                          # gradients take the storage type of their tensors
+        d_content = torch.empty(B, S, H * dc, dtype=ctx.content_dtype, device=xr.device) if dc > 0 else None
+        d_if = _zeros((dr // 2,), table)
         be.rope_bwd(dout, xr, table, d_content, d_xr, d_if, B, S, H, dc, dr)
-        return d_content, d_xr, d_if, None
+        return d_content, d_xr, d_if, None, None
 
 
 class LatentMaskAttentionFn(Function):
@@ -581,6 +587,76 @@ class LatentMaskAttentionFn(Function):
         be.gemm(dR, q, dk, Skv, D, Sq, (1, Skv, Sq * Skv, 0), (1, D, Sq * D, 0), (D, Skv * D, 0), batch=(B, 1),
                 accumulate=True)
         return dq, dk, dv, dW1, db1, dW2, db2, None, None, None, None, None, None, None
+
+
+class LatentMaskAttention16Fn(Function):
+    """The same attention on the bf16 matrix pipe (bf16 pipeline; backend.attn16_supported): q, k, v, the output and
+    every saved tensor are bf16, the probabilities are never stored (row log-sum-exp saved, P recomputed in backward).
+    q, k, v: [B,S,H*hd] bf16."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, q, k, v, w1, b1, w2, b2, u1, v1, s1, u2, v2, s2, H):
+        be = get_backend()
+        q, k, v = _c(q), _c(k), _c(v)
+        B, S, D = q.shape
+        hd = D // H
+        dev = q.device
+        w1o, w2o = _wop(w1), _wop(w2)
+        if w1o.dtype != torch.bfloat16 or w2o.dtype != torch.bfloat16:
+            raise RuntimeError("bf16 attention needs the step's bf16 weight copies (spectral_norm._refresh_bf16_weights)")
+        bf = lambda *shape: torch.empty(shape, dtype=torch.bfloat16, device=dev)
+        out, R, hp, hg, Mk, MkT = bf(B, S, D), bf(B, S, S), bf(B * S, 2 * S), bf(B * S, 2 * S), bf(B, S, S), bf(B, S, S)
+        lse = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+        be.attn16_fwd(q, k, v, w1o, b1, s1, w2o, b2, s2, out, R, hp, hg, Mk, MkT, lse, B, S, H, hd)
+        ctx.H = H
+        ctx.defer = (_deferred(w1), _deferred(w2))
+        ctx.wops = (w1o, w2o)
+        ctx.save_for_backward(q, k, v, out, R, hp, hg, Mk, MkT, lse, w1, w2, u1, v1, s1, u2, v2, s2)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    @_amp_bwd
+    def backward(ctx, dout):
+        be = get_backend()
+        q, k, v, out, R, hp, hg, Mk, MkT, lse, w1, w2, u1, v1, s1, u2, v2, s2 = ctx.saved_tensors
+        w1o, w2o = ctx.wops
+        H = ctx.H
+        B, S, D = q.shape
+        hd = D // H
+        dev = q.device
+        dout = _c(dout)
+        if dout.dtype != torch.bfloat16:
+            dout = dout.to(torch.bfloat16)
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        dM = torch.empty(B * S, S, dtype=torch.bfloat16, device=dev)
+        delta = torch.empty(B, H, S, dtype=torch.float32, device=dev)
+        be.attn16_bwd(q, k, v, out, dout, Mk, MkT, lse, delta, dq, dk, dv, dM, B, S, H, hd)
+        # mask MLP backward: typed GEMMs on the bf16 tensors
+        G2 = _zeros_big(w2.shape, w2)
+        _lin_wgrad(be, dM, hg, G2)
+        dW2, _ = _sn_wbwd(be, G2, w2, u2, v2, s2, defer=ctx.defer[1])
+        db2 = _colsum(be, dM)
+        dhp = torch.empty_like(hp)
+        _lin_dgrad(be, dM, w2o, s2, dhp, act=ACT_GELU_BWD, aux=hp)
+        R2 = R.view(B * S, S)
+        G1 = _zeros_big(w1.shape, w1)
+        _lin_wgrad(be, dhp, R2, G1)
+        dW1, _ = _sn_wbwd(be, G1, w1, u1, v1, s1, defer=ctx.defer[0])
+        db1 = _colsum(be, dhp)
+        dR = torch.empty(B, S, S, dtype=torch.bfloat16, device=dev)
+        _lin_dgrad(be, dhp, w1o, s1, dR.view(B * S, S))
+        # dQ_all += dR K_all ; dK_all += dR^T Q_all  (accumulated into the bf16 gradients)
+        be.gemm(dR, k, dq, S, D, S, (S, 1, S * S, 0), (1, D, S * D, 0), (D, S * D, 0), batch=(B, 1), accumulate=True)
+        be.gemm(dR, q, dk, S, D, S, (1, S, S * S, 0), (1, D, S * D, 0), (D, S * D, 0), batch=(B, 1), accumulate=True)
+        return dq, dk, dv, dW1, db1, dW2, db2, None, None, None, None, None, None, None
+
+
+def use_attention16(S, H, hd):
+    """The bf16 attention kernels serve this block: bf16 pipeline on, shape supported, token width a multiple of 8
+    (q / k / v are also operands of the batched dR products)."""
+    return bf16_pipeline() and (H * hd) % 8 == 0 and get_backend().attn16_supported(S, H, hd)
 
 
 class LatentFn(Function):

@@ -71,10 +71,10 @@ class SNLinear(SpectralWeight):
         super().__init__((out_features, in_features), bias=bias)
         self.in_features, self.out_features = in_features, out_features
 
-    def forward(self, x, act=0, ls=None, residual=None):
+    def forward(self, x, act=0, ls=None, residual=None, out16=False):
         from .ops import SNLinearFn
         return SNLinearFn.apply(x, self.weight_orig, self.bias, ls, residual, self.weight_u, self.weight_v,
-                                self.sigma(), act)
+                                self.sigma(), act, out16)
 
     def extra_repr(self):
         return f"in_features={self.in_features}, out_features={self.out_features}, bias={self.bias is not None}"

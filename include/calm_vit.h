@@ -146,12 +146,16 @@ int calm_layernorm_bwd(const void* dy, const float* x, const float* w, const flo
  * table: [2, S, dr/2] workspace; fwd fills it with cos|sin(t * inv_freq) (rebuilt every forward
  * because inv_freq is a learned parameter, Vi_Tools:70-71,86-91) and bwd reads it back.
  * bwd: d_content, d_xr from d_out; d_inv_freq[dr/2] += ... (atomics; caller zeroes).
+ * Each tensor may be fp32 or bf16 (type arguments): in the bf16 pipeline the projections write bf16 and the
+ * attention reads bf16 q / k; the rotation itself, the table and d_inv_freq are fp32.
  * ------------------------------------------------------------------------------------- */
-int calm_rope_fwd(const float* content, const float* xr, const float* inv_freq, float* table, float* out,
-                  int32_t B, int32_t S, int32_t H, int32_t dc, int32_t dr, void* stream);
-int calm_rope_bwd(const float* d_out, const float* xr, const float* table,
-                  float* d_content, float* d_xr, float* d_inv_freq,
-                  int32_t B, int32_t S, int32_t H, int32_t dc, int32_t dr, void* stream);
+int calm_rope_fwd(const void* content, const void* xr, const float* inv_freq, float* table, void* out,
+                  int32_t B, int32_t S, int32_t H, int32_t dc, int32_t dr,
+                  int32_t content_type, int32_t xr_type, int32_t out_type /* CALM_ST_*, ABI v4 */, void* stream);
+int calm_rope_bwd(const void* d_out, const void* xr, const float* table,
+                  void* d_content, void* d_xr, float* d_inv_freq,
+                  int32_t B, int32_t S, int32_t H, int32_t dc, int32_t dr,
+                  int32_t dout_type, int32_t xr_type, int32_t dcontent_type, int32_t dxr_type, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Row softmax of the masked logits and its backward (the softmax inside
@@ -192,6 +196,26 @@ int calm_attention_bwd_preferred(int32_t Sq, int32_t Skv, int32_t H, int32_t hd)
 int calm_attention_bwd(const float* q, const float* k, const float* v, const float* dout, const float* P, float* dS,
                        float* dq, float* dk, float* dv, float* dM, int32_t B, int32_t Sq, int32_t Skv, int32_t H,
                        int32_t hd, void* stream);
+
+/* ---------------------------------------------------------------------------------------
+ * The same attention on the bf16 matrix pipe (ABI v4; the bf16 pipeline — what autocast(bfloat16) makes of
+ * Vi_Tools:288-299): q, k, v, out and the saved R / hp / hg / Mk are bf16 tensors; w1 [2S,S] / w2 [S,2S] are the
+ * step's bf16 weight copies; biases, sigmas and the row log-sum-exp lse [B,H,S] are fp32.  Accumulation and softmax
+ * are fp32 (v_mfma_f32_16x16x32_bf16).  Every shape with S % 8 == 0, S <= 384, hd % 4 == 0, hd <= 128 is
+ * supported (keys padded to 32 in-kernel with mask -inf, head dims to 32 with zero columns).  The probabilities are
+ * NOT stored: the backward recomputes them from q, k, the mask and lse.  The mask is saved twice, Mk [B,query,key]
+ * and MkT [B,key,query] (the query-side / key-side backward passes keep queries / keys on the MFMA lanes).
+ *   calm_attention16_bwd: dq, dk, dv (bf16, written), dM [B,S,S] (bf16, written; the caller's mask-MLP backward
+ *   continues from it); delta [B,H,S] fp32 scratch (rowsum(dO o O) = rowsum(P o dP), written by the query-side
+ *   pass, read by the key-side pass); out = the forward's output.
+ * ------------------------------------------------------------------------------------- */
+int calm_attention16_supported(int32_t S, int32_t H, int32_t hd);
+int calm_attention16_fwd(const void* q, const void* k, const void* v, const void* w1, const float* b1, const float* s1,
+                         const void* w2, const float* b2, const float* s2, void* out, void* R, void* hp, void* hg,
+                         void* Mk, void* MkT, float* lse, int32_t B, int32_t S, int32_t H, int32_t hd, void* stream);
+int calm_attention16_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const void* Mk,
+                         const void* MkT, const float* lse, float* delta, void* dq, void* dk, void* dv, void* dM,
+                         int32_t B, int32_t S, int32_t H, int32_t hd, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Latent bottleneck sampling (Vi_Tools:232-242) + KL partial sum (Vi_Tools:24-25).

@@ -210,10 +210,10 @@ class EmulatedBackend:
         cos, sin = self._table(inv_freq, S)
         table.view(2, S, half)[0].copy_(cos)
         table.view(2, S, half)[1].copy_(sin)
-        x = xr.view(B, S, H, dr)
+        x = xr.view(B, S, H, dr).float()
         o = out.view(B, S, H, dc + dr)
         if dc:
-            o[..., :dc] = content.view(B, S, H, dc)
+            o[..., :dc] = content.view(B, S, H, dc).float()
         c, s = cos[None, :, None, :], sin[None, :, None, :]
         x1, x2 = x[..., :half], x[..., half:]
         o[..., dc:dc + half] = x1 * c - x2 * s
@@ -222,8 +222,8 @@ class EmulatedBackend:
     def rope_bwd(self, d_out, xr, table, d_content, d_xr, d_inv_freq, B, S, H, dc, dr):
         half = dr // 2
         cos, sin = table.view(2, S, half)[0], table.view(2, S, half)[1]
-        g = d_out.view(B, S, H, dc + dr)
-        x = xr.view(B, S, H, dr)
+        g = d_out.view(B, S, H, dc + dr).float()
+        x = xr.view(B, S, H, dr).float()
         if dc:
             d_content.view(B, S, H, dc).copy_(g[..., :dc])
         c, s = cos[None, :, None, :], sin[None, :, None, :]
@@ -272,6 +272,52 @@ class EmulatedBackend:
         Mk.view(B, Sq, Skv).copy_(mask)
         if P is not None:
             P.view(B, H, Sq, Skv).copy_(prob)
+
+    # ---- bf16 attention (calm_attention16_*): the rounding points of csrc/attention_bf16.hip -------------------------
+    def attn16_supported(self, S, H, hd):
+        return S % 8 == 0 and S <= 384 and hd % 4 == 0 and hd <= 128
+
+    @staticmethod
+    def _attn16_probs(q, k, Mk, lse, B, S, H, hd):
+        """P recomputed as the backward kernels do: exp(scale q k^T + mask - lse), all in fp32 from bf16 tensors."""
+        qh, kh = (t.float().view(B, S, H, hd).transpose(1, 2) for t in (q, k))
+        logits = qh @ kh.transpose(-1, -2) * (1.0 / math.sqrt(hd)) + Mk.float().view(B, 1, S, S)
+        return torch.exp(logits - lse.view(B, H, S, 1))
+
+    def attn16_fwd(self, q, k, v, w1, b1, s1, w2, b2, s2, out, R, hp, hg, Mk, MkT, lse, B, S, H, hd):
+        D = H * hd
+        q3, k3 = q.float().view(B, S, D), k.float().view(B, S, D)
+        R.view(B, S, S).copy_(q3 @ k3.transpose(1, 2))                       # fp32 accumulate, stored (and used) as bf16
+        pre = (R.float().view(B, S, S) @ w1.float().t()) * (1.0 / s1) + b1
+        hp.view(B, S, 2 * S).copy_(pre)
+        hg.view(B, S, 2 * S).copy_(_gelu(pre))                               # GELU of the fp32 pre-activation
+        mask = (hg.float().view(B, S, 2 * S) @ w2.float().t()) * (1.0 / s2) + b2
+        Mk.view(B, S, S).copy_(mask)                                         # the softmax adds the ROUNDED mask
+        MkT.view(B, S, S).copy_(Mk.view(B, S, S).transpose(1, 2))
+        qh, kh, vh = (t.float().view(B, S, H, hd).transpose(1, 2) for t in (q, k, v))
+        logits = qh @ kh.transpose(-1, -2) * (1.0 / math.sqrt(hd)) + Mk.float().view(B, 1, S, S)
+        mx = logits.max(dim=-1, keepdim=True).values
+        e = torch.exp(logits - mx)
+        sm = e.sum(dim=-1, keepdim=True)
+        lse.view(B, H, S).copy_((mx + torch.log(sm)).squeeze(-1))
+        P = (e * (1.0 / sm)).bfloat16().float()                              # P.V runs on bf16 probabilities
+        out.view(B, S, D).copy_((P @ vh).transpose(1, 2).reshape(B, S, D))
+
+    def attn16_bwd(self, q, k, v, out, dout, Mk, MkT, lse, delta, dq, dk, dv, dM, B, S, H, hd):
+        D = H * hd
+        sc = 1.0 / math.sqrt(hd)
+        qh, kh, vh, oh, doh = (t.float().view(B, S, H, hd).transpose(1, 2) for t in (q, k, v, out, dout))
+        assert torch.equal(MkT.view(B, S, S), Mk.view(B, S, S).transpose(1, 2))
+        P = self._attn16_probs(q, k, Mk, lse, B, S, H, hd)
+        dP = doh @ vh.transpose(-1, -2)
+        dl = (doh * oh).sum(dim=-1, keepdim=True)            # = rowsum(P o dP) up to the bf16 rounding of the output
+        delta.view(B, H, S).copy_(dl.squeeze(-1))
+        dS = P * (dP - dl)
+        dM.view(B, S, S).copy_(dS.sum(dim=1))
+        Pb, dSb = P.bfloat16().float(), dS.bfloat16().float()                # operands of the four output products
+        dq.view(B, S, D).copy_(((dSb @ kh) * sc).transpose(1, 2).reshape(B, S, D))
+        dk.view(B, S, D).copy_(((dSb.transpose(-1, -2) @ qh) * sc).transpose(1, 2).reshape(B, S, D))
+        dv.view(B, S, D).copy_((Pb.transpose(-1, -2) @ doh).transpose(1, 2).reshape(B, S, D))
 
     def attn_bwd_preferred(self, Sq, Skv, H, hd):
         return self.attn_fwd_supported(Sq, Skv, H, hd) and hd <= 64
