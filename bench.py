@@ -49,8 +49,8 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0
 # per precision: (dtype label, matrix-pipe peak for the ALGORITHMIC flops, kernel label)
 PRECISION_INFO = {
     "fp32": ("f32", PEAK_FP32_MATRIX_TFLOPS, "gemm_f32_kernel (calm_gemm, v_mfma_f32_32x32x2_f32)"),
-    "bf16": ("bf16 operands / f32 accumulate (f32 tensors)", PEAK_BF16_DENSE_TFLOPS,
-             "gemm_bf16c_kernel<1> (calm_gemm, v_mfma_f32_32x32x16_bf16)"),
+    "bf16": ("bf16 (bf16 GEMM / attention tensors, f32 accumulate, f32 residual stream and parameters)",
+             PEAK_BF16_DENSE_TFLOPS, "gemm_bf16w_kernel / gemm_bf16c_kernel (calm_gemm, v_mfma_f32_32x32x16_bf16)"),
     "bf16x3": ("f32 via bf16x3 split", PEAK_BF16_DENSE_TFLOPS / 3.0,
                "gemm_bf16c_kernel<3> (calm_gemm, 3 x v_mfma_f32_32x32x16_bf16 per product)"),
 }
@@ -123,25 +123,84 @@ class GemmProfiler:
         return flops, ms, len(self.records)
 
 
+class AttentionProfiler:
+    """HIP events around every fused-attention forward launch (fp32: calm_attention_fwd, bf16: calm_attention16_fwd);
+    algorithmic FLOPs per launch = B * (6 S^2 D + 8 S^3) (raw QK^T 2 S^2 D + mask MLP 8 S^3 + QK^T and
+    PV 4 S^2 D)."""
+
+    def __init__(self, be):
+        self.be, self.records = be, []
+        self.orig = {n: getattr(be, n) for n in ("attn_fwd", "attn16_fwd")}
+
+    def __enter__(self):
+        def wrap(name, dims):
+            fn = self.orig[name]
+
+            def timed(*a):
+                B, S, H, hd = dims(a)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn(*a)
+                e1.record()
+                self.records.append((float(B) * (6.0 * S * S * H * hd + 8.0 * S ** 3), e0, e1, (name, S, H, hd)))
+            return timed
+        self.be.attn_fwd = wrap("attn_fwd", lambda a: (a[15], a[16], a[18], a[19]))          # (..., B, Sq, Skv, H, hd)
+        self.be.attn16_fwd = wrap("attn16_fwd", lambda a: (a[16], a[17], a[18], a[19]))      # (..., B, S, H, hd)
+        return self
+
+    def __exit__(self, *exc):
+        for n, f in self.orig.items():
+            setattr(self.be, n, f)
+        return False
+
+    def summary(self):
+        torch.cuda.synchronize()
+        if not self.records:
+            return None
+        flops = sum(r[0] for r in self.records)
+        ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
+        big = max(self.records, key=lambda r: r[0])
+        same = [r for r in self.records if r[3] == big[3]]
+        return {"flops": flops, "ms": ms, "n": len(self.records), "largest": big[3],
+                "largest_us": 1e3 * sum(r[1].elapsed_time(r[2]) for r in same) / len(same),
+                "largest_tflops": big[0] / (1e-3 * sum(r[1].elapsed_time(r[2]) for r in same) / len(same)) / 1e12}
+
+
+def pmc_rows(kernel_prefix):
+    """(rows, source, stale) of the newest committed rocprofv3 PMC summary for kernels starting with `kernel_prefix`.
+    The summary carries a stamp (scripts/pmc_summary.py: sha256 of the kernel sources it was measured with); `stale` is
+    True when a source of calm-vit-dte_amd/csrc has changed since — the counters are then not reported."""
+    import csv
+    import glob
+    import hashlib
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.csv")), key=os.path.getmtime)
+    if not files:
+        return [], None, None
+    f = files[-1]
+    stale = True                                           # a summary without a stamp cannot be vouched for
+    if os.path.exists(f + ".stamp.json"):
+        stamp = json.load(open(f + ".stamp.json"))["sources_sha256"]
+        now = {os.path.basename(x): hashlib.sha256(open(x, "rb").read()).hexdigest()
+               for x in glob.glob(os.path.join(ROOT, "calm-vit-dte_amd", "csrc", "*"))}
+        stale = any(now.get(k) != v for k, v in stamp.items()) or set(now) != set(stamp)
+    rows = [r for r in csv.DictReader(open(f)) if r["kernel"].startswith(kernel_prefix)]
+    return rows, os.path.relpath(f, ROOT), stale
+
+
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC summary
     (profiles/*pmc_summary.csv: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate passes,
     scripts/gpu_pmc.sh) — the counters cannot be read from inside this process."""
-    import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.csv")))
-    if not files:
-        return None
+    rows, source, stale = pmc_rows(kernel_prefix)
     n = rd = wr = 0.0
-    for r in csv.DictReader(open(files[-1])):
-        if r["kernel"].startswith(kernel_prefix):
-            n += float(r["dispatches"])
-            rd += float(r["hbm_read_bytes(2xFETCH)"])
-            wr += float(r["hbm_write_bytes"])
-    if not n:
+    for r in rows:
+        n += float(r["dispatches"])
+        rd += float(r["hbm_read_bytes(2xFETCH)"])
+        wr += float(r["hbm_write_bytes"])
+    if not n or stale:                       # no summary / kernel sources changed since it was taken: report nothing
         return None
     return {"hbm_bytes_per_launch": round((rd + wr) / n), "read": round(rd / n), "write": round(wr / n),
-            "source": os.path.relpath(files[-1], ROOT)}
+            "source": source, "stale": stale}
 
 
 def cpu_baseline(wl, budget_s=15.0):
@@ -281,11 +340,14 @@ def main():
     if args.prof_steps > 0:
         # every rank runs the profiled steps (they contain the gradient all-reduce); only rank 0 records
         prof = GemmProfiler(calm.backend.get_backend()) if rank == 0 else None
+        aprof = AttentionProfiler(calm.backend.get_backend()) if rank == 0 else None
         if prof is not None:
             prof.__enter__()
+            aprof.__enter__()
         for _ in range(args.prof_steps):
             step(x, y)
         if prof is not None:
+            aprof.__exit__()
             prof.__exit__()
             flops, ms, n = prof.summary()
             if args.gemm_report:
@@ -300,10 +362,31 @@ def main():
                         "gemm_ms_per_step": round(ms / args.prof_steps, 2),
                         "algorithmic_gflop_per_step": round(flops / args.prof_steps / 1e9, 1)}
             # HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate passes) from the committed summary
-            detail = pmc_traffic("gemm_f32_kernel" if args.precision == "fp32" else "gemm_bf16c_kernel")
+            detail = pmc_traffic("gemm_f32_kernel" if args.precision == "fp32" else "gemm_bf16")
             if detail is not None:
                 roofline["traffic"] = detail["hbm_bytes_per_launch"]
                 roofline["traffic_detail"] = detail
+            # the axial-attention kernel (the other half of BASELINE.json's metric): live launch times of the fused
+            # forward + the MFMA utilisation / HBM rate of the committed PMC summary (refused when stale)
+            a = aprof.summary()
+            if a is not None:
+                name, aS, aH, ahd = a["largest"]
+                kname = "attn16_fwd_kernel" if name == "attn16_fwd" else "attn_fwd_kernel"
+                rows, source, stale = pmc_rows(kname)
+                best = max(rows, key=lambda r: float(r["gui_active_sum"])) if rows and not stale else None
+                attention = {"kernel": f"{kname} (fused latent-mask attention forward, "
+                                       f"{'v_mfma_f32_16x16x32_bf16' if name == 'attn16_fwd' else 'v_mfma_f32_16x16x4_f32'})",
+                             "bound": "mfma", "launches_per_step": a["n"] // args.prof_steps,
+                             "ms_per_step": round(a["ms"] / args.prof_steps, 3),
+                             "achieved": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2), "peak": round(peak, 1),
+                             "unit": "TFLOP/s", "frac": round(a["flops"] / (a["ms"] * 1e-3) / 1e12 / peak, 4),
+                             "largest_shape": {"S": aS, "H": aH, "hd": ahd, "avg_launch_us": round(a["largest_us"], 1),
+                                               "tflops": round(a["largest_tflops"], 2)},
+                             "mfma_util_pmc": round(float(best["mfma_util"]), 4) if best else None,
+                             "hbm_GBps_pmc": round(float(best["hbm_GBps"]), 1) if best else None,
+                             "pmc_kernel": best["kernel"] if best else None, "pmc_source": source, "pmc_stale": stale}
+            else:
+                attention = None
     if world > 1:
         dist.barrier()
 
@@ -325,6 +408,7 @@ def main():
             "model_tflops": round(value * wl["gflop_img"] / 1e3, 2),
             "hbm_peak_gib": round(torch.cuda.max_memory_allocated(device) / 2**30, 1),
             "roofline": roofline,
+            "attention": attention if roofline is not None else None,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)

@@ -112,7 +112,7 @@ SIGNATURES = {
     "calm_cnn_residual_bwd": (_i32, [_p] * 18 + [_i32, _i32, _i32, _p]),
     "calm_add": (_i32, [_p, _p, _p, _i64, _p]),
     "calm_gelu_bwd": (_i32, [_p, _p, _p, _i64, _p]),
-    "calm_colsum": (_i32, [_p, _p, _i64, _i32, _p]),
+    "calm_colsum": (_i32, [_p, _p, _i64, _i32, _i32, _p]),
     "calm_row_scale": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
     "calm_mean_seq_fwd": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "calm_mean_seq_bwd": (_i32, [_p, _p, _i32, _i32, _i32, _p]),

@@ -450,7 +450,7 @@ class HipBackend:
         _lib.check(self.lib.calm_gelu_bwd(_ptr(dy), _ptr(z), _ptr(dz), n, _stream()), "calm_gelu_bwd")
 
     def colsum(self, x, out, rows, cols):
-        _lib.check(self.lib.calm_colsum(_ptr(x), _ptr(out), rows, cols, _stream()), "calm_colsum")
+        _lib.check(self.lib.calm_colsum(_ptr(x, bf16_ok=True), _ptr(out), rows, cols, _st(x), _stream()), "calm_colsum")
 
     def row_scale(self, x, s, out, rows, cols):
         _lib.check(self.lib.calm_row_scale(_ptr(x), _ptr(s), _ptr(out, bf16_ok=True), rows, cols, _st(out), _stream()),

@@ -86,22 +86,62 @@ __device__ __forceinline__ bf16x8 row_frag(const __bf16* __restrict__ row, int c
     return cat8(a, b);
 }
 
-// NP = pairs of 16-key tiles (keys padded to 32 NP)
-template <int NP>
-__global__ __launch_bounds__(512) void attn16_fwd_kernel(const Attn16P p) {
-    constexpr int NJ = 2 * NP, SP = 32 * NP;
+// waves per workgroup as a function of the key-tile pairs: the 2 NP query tiles of one image split evenly over at most
+// 8-wave workgroups (compile-time, so that the per-thread share of every staged block is a constant).  Measured at
+// S = 224 (14 tiles): 2 x 7 waves 601 us forward, 3 x 5 waves (two workgroups per CU, but 1.5 rounds of them) 867 us.
+__host__ __device__ constexpr int waves_for(int np) {
+    return (2 * np + (2 * np + 7) / 8 - 1) / ((2 * np + 7) / 8);
+}
+
+// Register-staged copy of a [rows_img x cols_img] block: `load` issues the global reads into NV 8-byte vectors per
+// thread (zero-fill outside the valid region), `store` writes them to the LDS image — a chunk's loads are issued
+// before the MFMAs of the previous chunk and only waited for when the next image is built.
+template <int NV, int NTH>
+struct BlockStage {
+    bf16x4 v[NV];
+    __device__ __forceinline__ void load(const __bf16* __restrict__ src, long gstride, int rows_valid, int cols_valid,
+                                         int rows_img, int cols_img) {
+        const int per_row = cols_img >> 2;
+        const int total = rows_img * per_row;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int f = threadIdx.x + u * NTH;
+            const int row = f / per_row, c4 = 4 * (f - row * per_row);
+            bf16x4 x = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            if (f < total && row < rows_valid && c4 < cols_valid) x = ld4(src + (long)row * gstride + c4);
+            v[u] = x;
+        }
+    }
+    __device__ __forceinline__ void store(__bf16* __restrict__ dst, int ld, int rows_img, int cols_img) const {
+        const int per_row = cols_img >> 2;
+        const int total = rows_img * per_row;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int f = threadIdx.x + u * NTH;
+            const int row = f / per_row, c4 = 4 * (f - row * per_row);
+            if (f < total) *reinterpret_cast<bf16x4*>(dst + row * ld + c4) = v[u];
+        }
+    }
+};
+
+// NP = pairs of 16-key tiles (keys padded to 32 NP), HDP = head dim padded to 32
+// two workgroups share a CU (one's load / barrier stalls under the other's MFMAs) when both fit at 3 waves per SIMD
+__host__ __device__ constexpr int fwd_waves_per_simd(int np) { return 2 * waves_for(np) <= 12 ? 3 : 2; }
+
+template <int NP, int HDP>
+__global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void attn16_fwd_kernel(const Attn16P p) {
+    constexpr int NJ = 2 * NP, SP = 32 * NP, NW = waves_for(NP), NTH = 64 * NW;
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g = lane >> 4;
     const int b = blockIdx.y;
     const int S = p.S, D = p.H * p.hd, hd = p.hd;
-    const int q_lane = blockIdx.x * (16 * (blockDim.x >> 6)) + 16 * wave + c16;     // this lane's query
+    const int q_lane = blockIdx.x * (16 * NW) + 16 * wave + c16;                    // this lane's query
     const bool q_ok = q_lane < S;
     const int q_ld = q_ok ? q_lane : S - 1;                                         // clamped: loads stay in range
     const __bf16* qrow = p.q + ((long)b * S + q_ld) * D;
     const __bf16* kb = p.k + (long)b * S * D;
     const __bf16* vb = p.v + (long)b * S * D;
-    const bf16x4 zero4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
 
     f32x4v acc[NJ];
     bf16x8 Rf[NP];                       // R^T (then the mask) of this wave's queries as packed B fragments
@@ -111,14 +151,22 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(const Attn16P p) {
 #pragma unroll
         for (int t = 0; t < NJ; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
         constexpr int LDK = ld_rt(32);
+        constexpr int NV = (SP * 8 + NTH - 1) / NTH;
         __bf16* img = smem16;
         const int nch = (D + 31) / 32;
+        BlockStage<NV, NTH> st;
+        st.load(kb, D, S, D, SP, 32);
+        bf16x8 bq_next = row_frag(qrow, 0, g, D);
 #pragma unroll 1
         for (int c = 0; c < nch; ++c) {
             __syncthreads();                                         // the previous chunk's reads are done
-            stage_block(img, LDK, kb + 32 * c, D, S, D - 32 * c, SP, 32);
-            const bf16x8 bq = row_frag(qrow, 32 * c, g, D);
+            st.store(img, LDK, SP, 32);
+            const bf16x8 bq = bq_next;
             __syncthreads();
+            if (c + 1 < nch) {                                       // next chunk's loads fly under this chunk's MFMAs
+                st.load(kb + 32 * (c + 1), D, S, D - 32 * (c + 1), SP, 32);
+                bq_next = row_frag(qrow, 32 * (c + 1), g, D);
+            }
 #pragma unroll
             for (int t = 0; t < NJ; ++t) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(img + (16 * t + c16) * LDK + 8 * g);
@@ -140,18 +188,26 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(const Attn16P p) {
         const float inv1 = 1.0f / p.s1[0], inv2 = 1.0f / p.s2[0];
         const int NH = 2 * S;
         constexpr int LD1 = ld_pt(SP), LD2 = ld_pt(32);
+        constexpr int NV = (SP * 8 + NTH - 1) / NTH;                 // both chunk images are SP x 32 elements
         __bf16* img1 = smem16;                                       // W1 chunk  [32 hidden][SP keys]
         __bf16* img2 = smem16 + 32 * LD1;                            // W2 chunk  [SP keys][32 hidden]
 #pragma unroll
         for (int t = 0; t < NJ; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
         const int nch = (NH + 31) / 32;
+        BlockStage<NV, NTH> s1, s2;
+        s1.load(p.w1, S, NH, S, 32, SP);
+        s2.load(p.w2, NH, S, NH, SP, 32);
 #pragma unroll 1
         for (int c = 0; c < nch; ++c) {
             const int n0 = 32 * c;
             __syncthreads();
-            stage_block(img1, LD1, p.w1 + (long)n0 * S, S, NH - n0, S, 32, SP);
-            stage_block(img2, LD2, p.w2 + n0, NH, S, NH - n0, SP, 32);
+            s1.store(img1, LD1, 32, SP);
+            s2.store(img2, LD2, SP, 32);
             __syncthreads();
+            if (c + 1 < nch) {
+                s1.load(p.w1 + (long)(n0 + 32) * S, S, NH - n0 - 32, S, 32, SP);
+                s2.load(p.w2 + n0 + 32, NH, S, NH - n0 - 32, SP, 32);
+            }
             f32x4v h0 = {0.f, 0.f, 0.f, 0.f}, h1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int pr = 0; pr < NP; ++pr) {
@@ -203,23 +259,17 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(const Attn16P p) {
                 m = (f32x4v){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
             }
             const bf16x4 m4 = pack4(m);
-            if (q_ok && j < S) {
-                *reinterpret_cast<bf16x4*>(Mrow + j) = m4;
-                // ... and transposed, MkT[b][key][query], for the key-side backward pass (keys on the lanes there)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p.MkT[((long)b * S + j + r) * S + q_lane] = m4[r];
-            }
+            if (q_ok && j < S) *reinterpret_cast<bf16x4*>(Mrow + j) = m4;
             acc[t] = unpack4(m4);
             if (t & 1) Rf[t >> 1] = cat8(pack4(acc[t - 1]), m4);
         }
     }
 
     // ================= phase 3: per head  softmax(scale K_h Q_h^T + M^T),  O^T = V_h^T P^T =================
-    const int hdp = (hd + 31) / 32 * 32;
-    const int LDH = ld_rt(hdp);
+    constexpr int hdp = HDP, LDH = ld_rt(HDP), nks = HDP / 32, ndt = HDP / 16;
     __bf16* imgK = smem16;
     __bf16* imgV = p.kv_shared ? smem16 : smem16 + SP * LDH;
-    const int nks = hdp / 32, ndt = hdp / 16;
+    const int q4 = c16 >> 2, p4 = c16 & 3;
 #pragma unroll 1
     for (int h = 0; h < p.H; ++h) {
         __syncthreads();                                             // previous head's (or phase 2's) reads are done
@@ -227,14 +277,16 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(const Attn16P p) {
         if (!p.kv_shared) stage_block(imgV, LDH, vb + h * hd, D, S, hd, SP, hdp);
 #pragma unroll
         for (int t = 0; t < NJ; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        bf16x8 bq[nks];
+#pragma unroll
+        for (int ks = 0; ks < nks; ++ks) bq[ks] = row_frag(qrow + h * hd, 32 * ks, g, hd);
         __syncthreads();
-#pragma unroll 1
+#pragma unroll
         for (int ks = 0; ks < nks; ++ks) {
-            const bf16x8 bq = row_frag(qrow + h * hd, 32 * ks, g, hd);
 #pragma unroll
             for (int t = 0; t < NJ; ++t) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(imgK + (16 * t + c16) * LDH + 32 * ks + 8 * g);
-                acc[t] = MFMA_BF16(a, bq, acc[t]);
+                acc[t] = MFMA_BF16(a, bq[ks], acc[t]);
             }
         }
         if (p.kv_shared) {                                           // (uniform) V_h takes the image's place
@@ -267,12 +319,13 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(const Attn16P p) {
         sum += __shfl_xor(sum, 32, 64);
         const float inv = 1.0f / sum;
         if (q_ok && g == 0) p.lse[((long)b * p.H + h) * S + q_lane] = mx + __logf(sum);
+        // O^T[d,i] = sum_j V_h[j,d] P^T[j,i]: V^T fragments by transposed reads of the row-major [key][d] image.
+        // One output tile at a time (rolled loop): unrolled over the tiles the compiler hoists all NP x ndt transposed
+        // reads ahead of the products (+100 VGPRs, scratch).
         bf16x8 Pf[NP];
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) Pf[pr] = cat8(pack4(acc[2 * pr] * inv), pack4(acc[2 * pr + 1] * inv));
-        // O^T[d,i] = sum_j V_h[j,d] P^T[j,i]: V^T fragments by transposed reads of the row-major [key][d] image
         __bf16* orow = p.out + ((long)b * S + q_ld) * D + h * hd;
-        const int q4 = c16 >> 2, p4 = c16 & 3;
 #pragma unroll 1
         for (int dt = 0; dt < ndt; ++dt) {
             f32x4v o = {0.f, 0.f, 0.f, 0.f};
@@ -289,24 +342,55 @@ __global__ __launch_bounds__(512) void attn16_fwd_kernel(const Attn16P p) {
     }
 }
 
-template <int NP>
-int launch_fwd16(const Attn16P& p, int nw, size_t lds, hipStream_t s) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn16_fwd_kernel<NP>),
+// MkT[b][key][query] = Mk[b][query][key] for the key-side backward pass (keys on the lanes there).  A pass of its own:
+// written from the forward kernel's accumulators it is 8 NP scattered 2-byte stores per lane whose addresses cost the
+// kernel ~70 VGPRs at their peak.
+__global__ __launch_bounds__(256) void mask_transpose_kernel(const __bf16* __restrict__ in, __bf16* __restrict__ out, int S) {
+    __shared__ __bf16 tile[32][34];
+    const long base = (long)blockIdx.z * S * S;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8 threads, 32 x 32 tile
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        if (r < S && c < S) tile[ty + 8 * k][tx] = in[base + (long)r * S + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = c0 + ty + 8 * k, c = r0 + tx;                    // out row = in column
+        if (r < S && c < S) out[base + (long)r * S + c] = tile[tx][ty + 8 * k];
+    }
+}
+
+template <int NP, int HDP>
+int launch_fwd16_t(const Attn16P& p, size_t lds, hipStream_t s) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn16_fwd_kernel<NP, HDP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
+    constexpr int nw = waves_for(NP);
     const int tiles = (p.S + 15) / 16;
     dim3 grid((tiles + nw - 1) / nw, p.B);
-    hipLaunchKernelGGL((attn16_fwd_kernel<NP>), grid, dim3(64 * nw), lds, s, p);
+    hipLaunchKernelGGL((attn16_fwd_kernel<NP, HDP>), grid, dim3(64 * nw), lds, s, p);
+    CALM_LAUNCH_CHECK();
+    const int t32 = (p.S + 31) / 32;
+    hipLaunchKernelGGL(mask_transpose_kernel, dim3(t32, t32, p.B), dim3(256), 0, s, (const __bf16*)p.Mk, p.MkT, p.S);
     CALM_LAUNCH_CHECK();
     return 0;
 }
-
-// waves per workgroup: the query tiles of one image split evenly over at most 8-wave workgroups
-inline int pick_waves16(int S) {
-    const int tiles = (S + 15) / 16;
-    const int groups = (tiles + 7) / 8;
-    return (tiles + groups - 1) / groups;
+template <int NP>
+int launch_fwd16(const Attn16P& p, int, size_t lds, hipStream_t s) {
+    switch ((p.hd + 31) / 32) {
+        case 1: return launch_fwd16_t<NP, 32>(p, lds, s);
+        case 2: return launch_fwd16_t<NP, 64>(p, lds, s);
+        case 3: return launch_fwd16_t<NP, 96>(p, lds, s);
+        case 4: return launch_fwd16_t<NP, 128>(p, lds, s);
+    }
+    return CALM_E_UNSUPP;
 }
+
+// waves per workgroup of the backward kernels
+inline int pick_waves16(int S) { return waves_for((S + 31) / 32); }
 
 constexpr size_t LDS_BUDGET = 80 * 1024;       // two workgroups per CU when a kernel stays below this
 

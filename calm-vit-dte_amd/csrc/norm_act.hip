@@ -497,8 +497,8 @@ constexpr int COLSUM_MAXC = 4096;
 #ifndef COLSUM_GRID
 #define COLSUM_GRID 128      // A/B on [57344,448]: 66 us (scalar form) -> 28.6 us; 256 blocks: 39.6 (atomics), 128x256 threads: 34
 #endif
-__global__ __launch_bounds__(NT) void colsum_kernel(const float* __restrict__ x, float* __restrict__ out, long rows,
-                                                    int cols) {
+__global__ __launch_bounds__(NT) void colsum_kernel(const void* __restrict__ x, float* __restrict__ out, long rows,
+                                                    int cols, int x_type) {
     __shared__ float acc[COLSUM_MAXC];
     for (int c = threadIdx.x; c < cols; c += NT) acc[c] = 0.f;
     __syncthreads();
@@ -506,13 +506,13 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const float* __restrict__ x,
         // thread owns columns tid, tid+256, ...; block owns a strided set of rows
         for (int c = threadIdx.x; c < cols; c += NT) {
             float s = 0.f;
-            for (long r = blockIdx.x; r < rows; r += gridDim.x) s += x[r * cols + c];
+            for (long r = blockIdx.x; r < rows; r += gridDim.x) s += ldt(x, r * cols + c, x_type);
             acc[c] = s;
         }
     } else {
         const long total = rows * cols;
         for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT)
-            atomicAdd(&acc[(int)(i % cols)], x[i]);
+            atomicAdd(&acc[(int)(i % cols)], ldt(x, i, x_type));
     }
     __syncthreads();
     for (int c = threadIdx.x; c < cols; c += NT) atomicAdd(out + c, acc[c]);
@@ -521,9 +521,18 @@ __global__ __launch_bounds__(NT) void colsum_kernel(const float* __restrict__ x,
 // 16-byte form: TX lanes across the row (one float4 each, several passes if the row is longer), 1024/TX row lanes,
 // four rows in flight per thread; partial sums meet in LDS, one atomic per column per block.
 constexpr int CS_NT = 1024;          // 16 waves per block: few blocks (few atomics per column), many rows in flight
-template <int TX>
-__global__ __launch_bounds__(CS_NT) void colsum_vec_kernel(const float* __restrict__ x, float* __restrict__ out, long rows,
+// X16: x is a bf16 tensor (8-byte loads of 4 elements; the sums stay fp32)
+template <int TX, bool X16>
+__global__ __launch_bounds__(CS_NT) void colsum_vec_kernel(const void* __restrict__ x_, float* __restrict__ out, long rows,
                                                         int cols) {
+    auto ld = [&](long r, int c4) -> f32x4 {
+        if constexpr (X16) {
+            const bf16x4 v = reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(x_) + r * cols)[c4];
+            return (f32x4){(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+        } else {
+            return reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x_) + r * cols)[c4];
+        }
+    };
     constexpr int TY = CS_NT / TX;
     __shared__ f32x4 part[CS_NT];
     const int tx = threadIdx.x % TX, ty = threadIdx.x / TX;
@@ -534,12 +543,12 @@ __global__ __launch_bounds__(CS_NT) void colsum_vec_kernel(const float* __restri
         if (c4 < c4n) {
             long r = (long)blockIdx.x * TY + ty;
             for (; r + 3 * rstep < rows; r += 4 * rstep) {
-                a0 += reinterpret_cast<const f32x4*>(x + r * cols)[c4];
-                a1 += reinterpret_cast<const f32x4*>(x + (r + rstep) * cols)[c4];
-                a2 += reinterpret_cast<const f32x4*>(x + (r + 2 * rstep) * cols)[c4];
-                a3 += reinterpret_cast<const f32x4*>(x + (r + 3 * rstep) * cols)[c4];
+                a0 += ld(r, c4);
+                a1 += ld(r + rstep, c4);
+                a2 += ld(r + 2 * rstep, c4);
+                a3 += ld(r + 3 * rstep, c4);
             }
-            for (; r < rows; r += rstep) a0 += reinterpret_cast<const f32x4*>(x + r * cols)[c4];
+            for (; r < rows; r += rstep) a0 += ld(r, c4);
         }
         part[threadIdx.x] = (a0 + a1) + (a2 + a3);
         __syncthreads();
@@ -772,9 +781,11 @@ int calm_gelu_bwd(const float* dy, const float* z, float* dz, int64_t n, void* s
     return 0;
 }
 
-int calm_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* stream) {
+int calm_colsum(const void* x, float* out, int64_t rows, int32_t cols, int32_t x_type, void* stream) {
     if (!x || !out || rows <= 0 || cols <= 0) return CALM_E_INVAL;
+    if (!st_ok(x_type)) return CALM_E_INVAL;
     if (cols > COLSUM_MAXC) return CALM_E_UNSUPP;
+    const bool x16 = x_type == CALM_ST_BF16;
     if ((cols & 3) == 0 && aligned16(x) && rows >= 64) {
         const int c4n = cols >> 2;
         const int tx = c4n <= 32 ? 32 : c4n <= 64 ? 64 : c4n <= 128 ? 128 : 256;
@@ -782,18 +793,24 @@ int calm_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* st
         long gl = (rows + (long)ty * 8 - 1) / ((long)ty * 8);          // >= 8 rows per row lane
         const int gv = (int)(gl < 1 ? 1 : gl > COLSUM_GRID ? COLSUM_GRID : gl);   // few blocks: every block ends in `cols` atomics
         hipStream_t s = as_stream(stream);
+#define CS_LAUNCH(TXV)                                                                                              \
+    do {                                                                                                            \
+        if (x16) hipLaunchKernelGGL((colsum_vec_kernel<TXV, true>), dim3(gv), dim3(CS_NT), 0, s, x, out, (long)rows, cols); \
+        else hipLaunchKernelGGL((colsum_vec_kernel<TXV, false>), dim3(gv), dim3(CS_NT), 0, s, x, out, (long)rows, cols);    \
+    } while (0)
         switch (tx) {
-            case 32: hipLaunchKernelGGL(colsum_vec_kernel<32>, dim3(gv), dim3(CS_NT), 0, s, x, out, (long)rows, cols); break;
-            case 64: hipLaunchKernelGGL(colsum_vec_kernel<64>, dim3(gv), dim3(CS_NT), 0, s, x, out, (long)rows, cols); break;
-            case 128: hipLaunchKernelGGL(colsum_vec_kernel<128>, dim3(gv), dim3(CS_NT), 0, s, x, out, (long)rows, cols); break;
-            default: hipLaunchKernelGGL(colsum_vec_kernel<256>, dim3(gv), dim3(CS_NT), 0, s, x, out, (long)rows, cols); break;
+            case 32: CS_LAUNCH(32); break;
+            case 64: CS_LAUNCH(64); break;
+            case 128: CS_LAUNCH(128); break;
+            default: CS_LAUNCH(256); break;
         }
+#undef CS_LAUNCH
         CALM_LAUNCH_CHECK();
         return 0;
     }
     int g = cols >= NT ? (int)(rows < 512 ? rows : 512) : grid_for(rows * cols, NT * 8);
     if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(colsum_kernel, dim3(g), dim3(NT), 0, as_stream(stream), x, out, (long)rows, cols);
+    hipLaunchKernelGGL(colsum_kernel, dim3(g), dim3(NT), 0, as_stream(stream), x, out, (long)rows, cols, x_type);
     CALM_LAUNCH_CHECK();
     return 0;
 }

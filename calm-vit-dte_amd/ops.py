@@ -153,10 +153,8 @@ def _gop(be, g2):
 
 
 def _colsum(be, x2):
-    if x2.dtype != torch.float32:
-        x2 = x2.float()                     # bias gradients of bf16 tensors: not on the model's path (its MLPs have no bias)
-    out = _zeros((x2.shape[1],), x2)
-    be.colsum(x2, out, x2.shape[0], x2.shape[1])
+    out = _zeros((x2.shape[1],), x2 if x2.dtype == torch.float32 else x2.new_empty(0, dtype=torch.float32))
+    be.colsum(x2, out, x2.shape[0], x2.shape[1])            # fp32 column sums of a fp32 or bf16 tensor
     return out
 
 

@@ -388,7 +388,7 @@ int calm_cnn_residual_bwd(const float* dy, const float* x, const float* w0, cons
  * ------------------------------------------------------------------------------------- */
 int calm_add(const float* a, const float* b, float* out, int64_t n, void* stream);
 int calm_gelu_bwd(const float* dy, const float* z, float* dz, int64_t n, void* stream);
-int calm_colsum(const float* x, float* out, int64_t rows, int32_t cols, void* stream);
+int calm_colsum(const void* x, float* out, int64_t rows, int32_t cols, int32_t x_type /* CALM_ST_* */, void* stream);
 int calm_row_scale(const float* x, const float* s, void* out, int32_t rows, int32_t cols, int32_t out_type /* CALM_ST_* */,
                    void* stream);
 int calm_mean_seq_fwd(const float* x, float* y, int32_t B, int32_t S, int32_t D, void* stream);

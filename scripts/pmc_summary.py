@@ -4,8 +4,10 @@ MFMA utilisation and HBM traffic as /opt/skills/guides/MI355X_MICROARCH.md presc
   * SQ_VALU_MFMA_BUSY_CYCLES counts cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs
       mfma_util = MFMA_BUSY / (GUI_ACTIVE/8 * 256 CUs * 4 SIMDs)
   * FETCH_SIZE (KB) under-reports wide coalesced reads by exactly 2x on gfx950 -> doubled; WRITE_SIZE (KB) exact.
+Also writes OUT.csv.stamp.json: sha256 of every kernel source (calm-vit-dte_amd/csrc/*) the counters were taken with —
+bench.py refuses counter values whose kernel source has changed since.
 usage: pmc_summary.py OUT.csv DIR [DIR ...]"""
-import csv, glob, os, sys
+import csv, glob, hashlib, json, os, sys
 from collections import defaultdict
 
 out, dirs = sys.argv[1], sys.argv[2:]
@@ -42,3 +44,9 @@ with open(out, "w") as f:
         f.write(f"\"{k}\",{n},{gui:.0f},{c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.0f},{util:.4f},{rd:.0f},{wr:.0f},{t:.6f},{bw:.1f}\n")
 for gui, k, n, util, rd, wr, t, c in rows[:16]:
     print(f"{k[:58]:58s} n={n:5d} mfma_util={100*util:5.1f}%  rd={rd/1e9:8.2f}GB wr={wr/1e9:8.2f}GB t={1e3*t:8.2f}ms")
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+stamp = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest()
+         for f in sorted(glob.glob(os.path.join(root, "calm-vit-dte_amd", "csrc", "*")))}
+with open(out + ".stamp.json", "w") as f:
+    json.dump({"sources_sha256": stamp, "argv": sys.argv[1:]}, f, indent=1, sort_keys=True)

@@ -442,7 +442,7 @@ class EmulatedBackend:
         dz.copy_(dy * _gelu_grad(z))
 
     def colsum(self, x, out, rows, cols):
-        out.add_(x.reshape(rows, cols).sum(dim=0))
+        out.add_(x.reshape(rows, cols).float().sum(dim=0))
 
     def row_scale(self, x, s, out, rows, cols):
         out.view(rows, cols).copy_(x.reshape(rows, cols) * s[:, None])
