@@ -126,7 +126,12 @@ struct BlockStage {
 
 // NP = pairs of 16-key tiles (keys padded to 32 NP), HDP = head dim padded to 32
 // two workgroups share a CU (one's load / barrier stalls under the other's MFMAs) when both fit at 3 waves per SIMD
-__host__ __device__ constexpr int fwd_waves_per_simd(int np) { return 2 * waves_for(np) <= 12 ? 3 : 2; }
+#ifndef ATT16_FWD_OCC3
+#define ATT16_FWD_OCC3 0     // A/B'd: constraining the registers for a second workgroup per CU spills (S=176: 367 vs 240 us)
+#endif
+__host__ __device__ constexpr int fwd_waves_per_simd(int np) {
+    return (ATT16_FWD_OCC3 && 2 * waves_for(np) <= 12 && np <= 6) ? 3 : 2;
+}
 
 template <int NP, int HDP>
 __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void attn16_fwd_kernel(const Attn16P p) {
@@ -267,20 +272,35 @@ __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void at
 
     // ================= phase 3: per head  softmax(scale K_h Q_h^T + M^T),  O^T = V_h^T P^T =================
     constexpr int hdp = HDP, LDH = ld_rt(HDP), nks = HDP / 32, ndt = HDP / 16;
+    constexpr int NVH = (SP * HDP / 4 + NTH - 1) / NTH;             // 8-byte vectors per thread per head image
     __bf16* imgK = smem16;
     __bf16* imgV = p.kv_shared ? smem16 : smem16 + SP * LDH;
     const int q4 = c16 >> 2, p4 = c16 & 3;
+    // K_h / V_h of the NEXT head are fetched into registers while this head computes (both images resident case)
+    BlockStage<NVH, NTH> sk, sv;
+    if (!p.kv_shared) {
+        sk.load(kb, D, S, hd, SP, hdp);
+        sv.load(vb, D, S, hd, SP, hdp);
+    }
 #pragma unroll 1
     for (int h = 0; h < p.H; ++h) {
         __syncthreads();                                             // previous head's (or phase 2's) reads are done
-        stage_block(imgK, LDH, kb + h * hd, D, S, hd, SP, hdp);
-        if (!p.kv_shared) stage_block(imgV, LDH, vb + h * hd, D, S, hd, SP, hdp);
+        if (!p.kv_shared) {
+            sk.store(imgK, LDH, SP, hdp);
+            sv.store(imgV, LDH, SP, hdp);
+        } else {
+            stage_block(imgK, LDH, kb + h * hd, D, S, hd, SP, hdp);
+        }
 #pragma unroll
         for (int t = 0; t < NJ; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
         bf16x8 bq[nks];
 #pragma unroll
         for (int ks = 0; ks < nks; ++ks) bq[ks] = row_frag(qrow + h * hd, 32 * ks, g, hd);
         __syncthreads();
+        if (!p.kv_shared && h + 1 < p.H) {
+            sk.load(kb + (h + 1) * hd, D, S, hd, SP, hdp);
+            sv.load(vb + (h + 1) * hd, D, S, hd, SP, hdp);
+        }
 #pragma unroll
         for (int ks = 0; ks < nks; ++ks) {
 #pragma unroll
@@ -432,6 +452,13 @@ struct Attn16BP {
     int ch;             // tile pairs per LDS chunk
 };
 
+// tile pairs whose two images fit the LDS budget of a workgroup (two workgroups per CU)
+__host__ __device__ constexpr int bwd_chunk_pairs_c(int np, int hdp) {
+    const int per_pair = 2 * 32 * ld_rt(hdp) * 2;
+    const int ch = (80 * 1024) / per_pair;
+    return ch < 1 ? 1 : ch > np ? np : ch;
+}
+
 // Both kernels are compiled per (NP, HDP = head dim padded to 32): with run-time trip counts the fully unrolled
 // tile loops (register-array indices must be constants) cost > 256 VGPRs and kilobytes of scratch.
 
@@ -443,7 +470,7 @@ __device__ __forceinline__ void stage_pair_images(__bf16* imgA, __bf16* imgB, in
 }
 
 template <int NP, int HDP>
-__global__ __launch_bounds__(512) void attn16_bwd_q_kernel(const Attn16BP p) {
+__global__ __launch_bounds__(64 * waves_for(NP)) void attn16_bwd_q_kernel(const Attn16BP p) {
     constexpr int NJ = 2 * NP;
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -467,6 +494,17 @@ __global__ __launch_bounds__(512) void attn16_bwd_q_kernel(const Attn16BP p) {
     f32x4v accM[NJ];
 #pragma unroll
     for (int t = 0; t < NJ; ++t) accM[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+    // one chunk per head (all keys resident): the NEXT head's K_h / V_h are fetched into registers under this head's math
+    // (only where the prefetch registers fit beside the 8 NP mask-gradient accumulators without spilling: NP x HDP <= 256)
+    constexpr int NTHB = 64 * waves_for(NP);
+    constexpr bool PRE = bwd_chunk_pairs_c(NP, HDP) == NP && NP * HDP <= 256;
+    constexpr int NVB = PRE ? (32 * NP * HDP / 4 + NTHB - 1) / NTHB : 1;
+    constexpr bool pre = PRE;
+    BlockStage<NVB, NTHB> sa, sb;
+    if (pre) {
+        sa.load(kb, D, S, hd, 32 * NP, hdp);
+        sb.load(vb, D, S, hd, 32 * NP, hdp);
+    }
 
 #pragma unroll 1
     for (int h = 0; h < p.H; ++h) {
@@ -496,8 +534,17 @@ __global__ __launch_bounds__(512) void attn16_bwd_q_kernel(const Attn16BP p) {
             const int lp = pr % p.ch;                      // uniform
             if (lp == 0) {
                 __syncthreads();
-                stage_pair_images(imgK, imgV, LDH, kb + h * hd, vb + h * hd, D, 32 * pr, S, hd, rows_img, hdp);
+                if (pre) {
+                    sa.store(imgK, LDH, 32 * NP, hdp);
+                    sb.store(imgV, LDH, 32 * NP, hdp);
+                } else {
+                    stage_pair_images(imgK, imgV, LDH, kb + h * hd, vb + h * hd, D, 32 * pr, S, hd, rows_img, hdp);
+                }
                 __syncthreads();
+                if (pre && h + 1 < p.H) {
+                    sa.load(kb + (h + 1) * hd, D, S, hd, 32 * NP, hdp);
+                    sb.load(vb + (h + 1) * hd, D, S, hd, 32 * NP, hdp);
+                }
             }
             f32x4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
 #pragma unroll
@@ -546,7 +593,7 @@ __global__ __launch_bounds__(512) void attn16_bwd_q_kernel(const Attn16BP p) {
 }
 
 template <int NP, int HDP>
-__global__ __launch_bounds__(512) void attn16_bwd_kv_kernel(const Attn16BP p) {
+__global__ __launch_bounds__(64 * waves_for(NP)) void attn16_bwd_kv_kernel(const Attn16BP p) {
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3;
@@ -566,6 +613,15 @@ __global__ __launch_bounds__(512) void attn16_bwd_kv_kernel(const Attn16BP p) {
     // the mask column of this lane's key (MkT[b][key][query]) is re-read (L2) pair by pair in every head
     const __bf16* Mcol = p.MkT + ((long)b * S + k_ld) * S;
     const bf16x4 zero4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+    constexpr int NTHB = 64 * waves_for(NP);
+    constexpr bool PRE = bwd_chunk_pairs_c(NP, HDP) == NP && NP * HDP <= 448;      // see the query-side kernel
+    constexpr int NVB = PRE ? (32 * NP * HDP / 4 + NTHB - 1) / NTHB : 1;
+    constexpr bool pre = PRE;
+    BlockStage<NVB, NTHB> sa, sb;
+    if (pre) {
+        sa.load(qb, D, S, hd, 32 * NP, hdp);
+        sb.load(dob, D, S, hd, 32 * NP, hdp);
+    }
 #pragma unroll 1
     for (int h = 0; h < p.H; ++h) {
         bf16x8 kf[MAXKS], vf[MAXKS];
@@ -587,8 +643,17 @@ __global__ __launch_bounds__(512) void attn16_bwd_kv_kernel(const Attn16BP p) {
             const int lp = pr % p.ch;
             if (lp == 0) {
                 __syncthreads();
-                stage_pair_images(imgQ, imgO, LDH, qb + h * hd, dob + h * hd, D, 32 * pr, S, hd, rows_img, hdp);
+                if (pre) {
+                    sa.store(imgQ, LDH, 32 * NP, hdp);
+                    sb.store(imgO, LDH, 32 * NP, hdp);
+                } else {
+                    stage_pair_images(imgQ, imgO, LDH, qb + h * hd, dob + h * hd, D, 32 * pr, S, hd, rows_img, hdp);
+                }
                 __syncthreads();
+                if (pre && h + 1 < p.H) {
+                    sa.load(qb + (h + 1) * hd, D, S, hd, 32 * NP, hdp);
+                    sb.load(dob + (h + 1) * hd, D, S, hd, 32 * NP, hdp);
+                }
             }
             f32x4v s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, d0 = s0, d1 = s0;
 #pragma unroll
@@ -640,14 +705,7 @@ __global__ __launch_bounds__(512) void attn16_bwd_kv_kernel(const Attn16BP p) {
     }
 }
 
-inline int bwd_chunk_pairs(int S, int hd) {
-    const int NP = (S + 31) / 32, hdp = (hd + 31) / 32 * 32;
-    const size_t per_pair = (size_t)2 * 32 * ld_rt(hdp) * sizeof(__bf16);
-    int ch = (int)(LDS_BUDGET / per_pair);
-    if (ch < 1) ch = 1;
-    if (ch > NP) ch = NP;
-    return ch;
-}
+inline int bwd_chunk_pairs(int S, int hd) { return bwd_chunk_pairs_c((S + 31) / 32, (hd + 31) / 32 * 32); }
 
 template <int NP, int HDP>
 int launch_bwd16_t(const Attn16BP& p, int nw, hipStream_t s) {
