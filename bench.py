@@ -37,8 +37,10 @@ WORKLOADS = {
                              seq_len_step=16, seq_len_reduce=40, out_features=1000), gflop_img=46.063, batch=256),
     "base224": dict(kw=dict(heads=12, seq_length=224, in_features=672, dim_step=48, mean_var_hidden=240,
                             seq_len_step=16, seq_len_reduce=80, out_features=1000), gflop_img=48.359, batch=256),
+    # bs=128: BASELINE config #4 names no batch; 128 images fill the chip (384 workgroups of the attention kernels) and
+    # use 45 of the 288 GB (round 1 ran bs=32: `--batch 32` reproduces it)
     "base384": dict(kw=dict(heads=12, seq_length=384, in_features=1152, dim_step=48, mean_var_hidden=240,
-                            seq_len_step=16, seq_len_reduce=80, out_features=1000), gflop_img=356.425, batch=32),
+                            seq_len_step=16, seq_len_reduce=80, out_features=1000), gflop_img=356.425, batch=128),
     "large224": dict(kw=dict(heads=6, seq_length=224, in_features=672, dim_step=24, mean_var_hidden=480,
                              seq_len_step=8, seq_len_reduce=160, out_features=1000), gflop_img=92.167, batch=128),
     "nano48": dict(kw=dict(heads=3, seq_length=48, in_features=144, dim_step=12, mean_var_hidden=24,
@@ -173,18 +175,19 @@ def pmc_rows(kernel_prefix):
     import csv
     import glob
     import hashlib
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.csv")), key=os.path.getmtime)
-    if not files:
-        return [], None, None
-    f = files[-1]
-    stale = True                                           # a summary without a stamp cannot be vouched for
-    if os.path.exists(f + ".stamp.json"):
-        stamp = json.load(open(f + ".stamp.json"))["sources_sha256"]
-        now = {os.path.basename(x): hashlib.sha256(open(x, "rb").read()).hexdigest()
-               for x in glob.glob(os.path.join(ROOT, "calm-vit-dte_amd", "csrc", "*"))}
-        stale = any(now.get(k) != v for k, v in stamp.items()) or set(now) != set(stamp)
-    rows = [r for r in csv.DictReader(open(f)) if r["kernel"].startswith(kernel_prefix)]
-    return rows, os.path.relpath(f, ROOT), stale
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.csv")))       # names sort by round
+    for f in reversed(files):                              # newest summary that has this kernel family
+        rows = [r for r in csv.DictReader(open(f)) if r["kernel"].startswith(kernel_prefix)]
+        if not rows:
+            continue
+        stale = True                                       # a summary without a stamp cannot be vouched for
+        if os.path.exists(f + ".stamp.json"):
+            stamp = json.load(open(f + ".stamp.json"))["sources_sha256"]
+            now = {os.path.basename(x): hashlib.sha256(open(x, "rb").read()).hexdigest()
+                   for x in glob.glob(os.path.join(ROOT, "calm-vit-dte_amd", "csrc", "*"))}
+            stale = any(now.get(k) != v for k, v in stamp.items()) or set(now) != set(stamp)
+        return rows, os.path.relpath(f, ROOT), stale
+    return [], None, None
 
 
 def pmc_traffic(kernel_prefix):

@@ -58,6 +58,8 @@ struct Attn16P {
     int kv_shared;      // K_h and V_h do not both fit in LDS: one image, V_h staged after the Q K^T products
 };
 
+constexpr size_t LDS_BUDGET = 80 * 1024;       // two workgroups per CU when a kernel stays below this
+
 // stride (in bf16 elements) of a [row][cols] image that is read by 16-byte fragments and by transposed reads
 __host__ __device__ constexpr int ld_rt(int cols) { return cols + 16; }        // cols % 32 == 0 -> bytes = 32 (mod 64)
 // ... of an image read in paired-tile order (two 8-byte reads per lane)
@@ -136,6 +138,7 @@ __host__ __device__ constexpr int fwd_waves_per_simd(int np) {
 template <int NP, int HDP>
 __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void attn16_fwd_kernel(const Attn16P p) {
     constexpr int NJ = 2 * NP, SP = 32 * NP, NW = waves_for(NP), NTH = 64 * NW;
+    constexpr bool KEEP_MASK = NP <= 8;
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g = lane >> 4;
@@ -268,28 +271,33 @@ __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void at
             acc[t] = unpack4(m4);
             if (t & 1) Rf[t >> 1] = cat8(pack4(acc[t - 1]), m4);
         }
+        if constexpr (!KEEP_MASK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // own mask stores before the re-reads
     }
 
     // ================= phase 3: per head  softmax(scale K_h Q_h^T + M^T),  O^T = V_h^T P^T =================
     constexpr int hdp = HDP, LDH = ld_rt(HDP), nks = HDP / 32, ndt = HDP / 16;
-    constexpr int NVH = (SP * HDP / 4 + NTH - 1) / NTH;             // 8-byte vectors per thread per head image
+    // K_h / V_h of the NEXT head are fetched into registers while this head computes — where both images are resident
+    // and the staging registers fit beside the accumulators without spilling (NP x HDP <= 640)
+    constexpr bool KV_SHARED = (size_t)2 * SP * LDH * sizeof(__bf16) > LDS_BUDGET;
+    constexpr bool PRE3 = !KV_SHARED && NP * HDP <= 640;
+    constexpr int NVH = PRE3 ? (SP * HDP / 4 + NTH - 1) / NTH : 1;   // 8-byte vectors per thread per head image
     __bf16* imgK = smem16;
-    __bf16* imgV = p.kv_shared ? smem16 : smem16 + SP * LDH;
+    __bf16* imgV = KV_SHARED ? smem16 : smem16 + SP * LDH;
     const int q4 = c16 >> 2, p4 = c16 & 3;
-    // K_h / V_h of the NEXT head are fetched into registers while this head computes (both images resident case)
     BlockStage<NVH, NTH> sk, sv;
-    if (!p.kv_shared) {
+    if (PRE3) {
         sk.load(kb, D, S, hd, SP, hdp);
         sv.load(vb, D, S, hd, SP, hdp);
     }
 #pragma unroll 1
     for (int h = 0; h < p.H; ++h) {
         __syncthreads();                                             // previous head's (or phase 2's) reads are done
-        if (!p.kv_shared) {
+        if (PRE3) {
             sk.store(imgK, LDH, SP, hdp);
             sv.store(imgV, LDH, SP, hdp);
         } else {
             stage_block(imgK, LDH, kb + h * hd, D, S, hd, SP, hdp);
+            if (!KV_SHARED) stage_block(imgV, LDH, vb + h * hd, D, S, hd, SP, hdp);
         }
 #pragma unroll
         for (int t = 0; t < NJ; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void at
 #pragma unroll
         for (int ks = 0; ks < nks; ++ks) bq[ks] = row_frag(qrow + h * hd, 32 * ks, g, hd);
         __syncthreads();
-        if (!p.kv_shared && h + 1 < p.H) {
+        if (PRE3 && h + 1 < p.H) {
             sk.load(kb + (h + 1) * hd, D, S, hd, SP, hdp);
             sv.load(vb + (h + 1) * hd, D, S, hd, SP, hdp);
         }
@@ -309,20 +317,36 @@ __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void at
                 acc[t] = MFMA_BF16(a, bq[ks], acc[t]);
             }
         }
-        if (p.kv_shared) {                                           // (uniform) V_h takes the image's place
+        if (KV_SHARED) {                                             // V_h takes the image's place
             __syncthreads();
             stage_block(imgV, LDH, vb + h * hd, D, S, hd, SP, hdp);
             __syncthreads();
         }
         // softmax over the keys: 4*NJ in-lane values, then the 4 lane groups (xor 16, xor 32)
         float mx = -INFINITY;
+        if constexpr (KEEP_MASK) {
 #pragma unroll
-        for (int t = 0; t < NJ; ++t) {
-            const bf16x8 mf = Rf[t >> 1];
+            for (int t = 0; t < NJ; ++t) {
+                const bf16x8 mf = Rf[t >> 1];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                acc[t][r] = fmaf(acc[t][r], p.scale, (float)mf[4 * (t & 1) + r]);
-                mx = fmaxf(mx, acc[t][r]);
+                for (int r = 0; r < 4; ++r) {
+                    acc[t][r] = fmaf(acc[t][r], p.scale, (float)mf[4 * (t & 1) + r]);
+                    mx = fmaxf(mx, acc[t][r]);
+                }
+            }
+        } else {
+            // long rows: the mask row (this lane's own stores of phase 2, L2-resident) is re-read per head instead of
+            // occupying 4 NP registers through the head loop
+            const __bf16* Mrow = p.Mk + ((long)b * S + q_ld) * S;
+#pragma unroll
+            for (int t = 0; t < NJ; ++t) {
+                const int j = 16 * t + 4 * g;
+                const bf16x4 m4 = j < S ? ld4(Mrow + j) : (bf16x4){(__bf16)-INFINITY, (__bf16)-INFINITY, (__bf16)-INFINITY, (__bf16)-INFINITY};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[t][r] = fmaf(acc[t][r], p.scale, (float)m4[r]);
+                    mx = fmaxf(mx, acc[t][r]);
+                }
             }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -411,8 +435,6 @@ int launch_fwd16(const Attn16P& p, int, size_t lds, hipStream_t s) {
 
 // waves per workgroup of the backward kernels
 inline int pick_waves16(int S) { return waves_for((S + 31) / 32); }
-
-constexpr size_t LDS_BUDGET = 80 * 1024;       // two workgroups per CU when a kernel stays below this
 
 // K_h and V_h images side by side when that leaves room for two workgroups per CU, else one shared image
 inline bool fwd_kv_shared(int S, int hd) {

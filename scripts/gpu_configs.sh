@@ -11,11 +11,13 @@ except Exception as e:
     print('FAILED', e)
 "; }
 rm -f gpurun_out/configs.jsonl
+run --workload small224
+run --workload small224 --precision bf16x3
+run --workload small224 --autocast
 run --workload base224
-run --workload base224 --precision bf16x3
-run --workload base224 --precision bf16
+run --workload base224 --autocast
 run --workload large224
-run --workload large224 --precision bf16
+run --workload large224 --autocast
 run --workload base384
-run --workload base384 --precision bf16
+run --workload base384 --autocast
 run --workload nano48
