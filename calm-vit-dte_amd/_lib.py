@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("CALM_VIT_LIB") or os.path.join(HERE, "libcalmvit_hip.
 
 ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 F32 = 0
-ST_F32, ST_BF16 = 0, 1   # storage type of a tensor in HBM (CALM_ST_*)
+ST_F32, ST_BF16, ST_FP8_E4M3, ST_FP8_E5M2 = 0, 1, 2, 3   # storage type of a tensor in HBM (CALM_ST_*)
 E_INVAL, E_LAYOUT, E_UNSUPP = -1, -2, -3      # CALM_E_*
 ABI_VERSION = 4          # CALM_ABI_VERSION of include/calm_vit.h
 
@@ -40,6 +40,7 @@ class GemmArgs(C.Structure):
         ("A_group", _p * 4), ("B_group", _p * 4), ("C_group", _p * 4), ("inv_scale_group", _p * 4),
         ("workspace", _p), ("workspace_bytes", _i64),
         ("a_type", _i32), ("b_type", _i32), ("c_type", _i32), ("aux_type", _i32), ("r_type", _i32), ("reserved_", _i32),
+        ("a_dq", _p), ("b_dq", _p),
     ]
 
 
@@ -82,6 +83,8 @@ SIGNATURES = {
     "calm_cast_chunk_elems": (_i32, []),
     "calm_cast_bf16": (_i32, [_p, _p, _i32, _p]),
     "calm_cast_bf16_one": (_i32, [_p, _p, _i64, _p]),
+    "calm_quantize_fp8": (_i32, [_p, _i32, _i64, _p, _i32, _p, _p]),
+    "calm_transpose_u8": (_i32, [_p, _p, _i32, _i32, _p]),
     "calm_rope_fwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "calm_rope_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
     "calm_softmax_fwd": (_i32, [_p, _i64, _i32, _p]),

@@ -22,14 +22,19 @@ SN_EPS = 1e-12
 # calm_gemm_args.dtype (include/calm_vit.h): which matrix pipe the GEMMs use.  Tensors are fp32 in every mode.
 GEMM_WORKSPACE = os.environ.get("CALM_GEMM_WORKSPACE", "1") != "0"      # A/B switch: 0 = split launches always use atomics
 BF16_STORAGE = os.environ.get("CALM_BF16_STORAGE", "1") != "0"          # A/B switch: 0 = fp32 tensors in bf16 mode too
-PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2}
+PRECISIONS = {"fp32": 0, "bf16": 1, "bf16x3": 2, "fp8": 1}     # calm_gemm_args.dtype; "fp8" = the bf16 pipeline with the
+                                                                # forward / input-gradient Linear GEMMs on fp8 operands
+FP8_DTYPES = (torch.float8_e4m3fn, torch.float8_e5m2)
 _precision = "fp32"
 
 
 def set_matmul_precision(name):
     """'fp32'   exact fp32 MFMA (default; BASELINE config #2, parity 1e-3 rel fp32 with margin 1e3)
     'bf16'   bf16 operands, fp32 accumulate (autocast(bfloat16) arithmetic; BASELINE configs #3-#5)
-    'bf16x3' bf16 hi/lo split, 3 MFMA passes: fp32-level results (~1e-5) on the bf16 matrix pipe"""
+    'bf16x3' bf16 hi/lo split, 3 MFMA passes: fp32-level results (~1e-5) on the bf16 matrix pipe
+    'fp8'    the bf16 pipeline with the forward and input-gradient products of the large Linear layers on per-tensor
+             scaled OCP fp8 operands (e4m3 activations / weights, e5m2 gradients; BASELINE config #5); weight gradients,
+             attention and everything else as in 'bf16'"""
     global _precision
     if name not in PRECISIONS:
         raise ValueError(f"unknown matmul precision {name!r}; choose from {sorted(PRECISIONS)}")
@@ -50,10 +55,16 @@ def effective_precision():
         if dt != torch.bfloat16:
             raise NotImplementedError(f"autocast dtype {dt} is not supported on this path (the reference uses bfloat16)")
         return "bf16"
-    return _precision
+    return "bf16" if _precision == "fp8" else _precision
 
 
-def _ptr(t, allow_none=False, bf16_ok=False):
+def fp8_linears():
+    """True when the Linear layers' forward / input-gradient GEMMs are to run on fp8 operands (set_matmul_precision('fp8');
+    also inside autocast(bfloat16), which then selects the bf16 pipeline around them)."""
+    return _precision == "fp8" and BF16_STORAGE
+
+
+def _ptr(t, allow_none=False, bf16_ok=False, fp8_ok=False):
     if t is None:
         if allow_none:
             return None
@@ -61,7 +72,7 @@ def _ptr(t, allow_none=False, bf16_ok=False):
     if not t.is_cuda:
         raise RuntimeError("CALM-ViT ops run only on the MI355X HIP path: got a CPU tensor "
                            "(there is no CPU fallback; move the model and inputs to 'cuda')")
-    if t.dtype != torch.float32 and not (bf16_ok and t.dtype == torch.bfloat16):
+    if t.dtype != torch.float32 and not (bf16_ok and t.dtype == torch.bfloat16) and not (fp8_ok and t.dtype in FP8_DTYPES):
         raise TypeError(f"fp32 tensor expected, got {t.dtype}")
     return t.data_ptr()
 
@@ -74,7 +85,10 @@ def _ptr16(t):
 
 def _st(t):
     """CALM_ST_* storage type of a tensor argument (None -> fp32)."""
-    return _lib.ST_BF16 if t is not None and t.dtype == torch.bfloat16 else _lib.ST_F32
+    if t is None:
+        return _lib.ST_F32
+    return {torch.bfloat16: _lib.ST_BF16, torch.float8_e4m3fn: _lib.ST_FP8_E4M3,
+            torch.float8_e5m2: _lib.ST_FP8_E5M2}.get(t.dtype, _lib.ST_F32)
 
 
 def bf16_pipeline():
@@ -174,7 +188,8 @@ class HipBackend:
     # ---- GEMM -------------------------------------------------------------------------
     def gemm(self, A, B, Cout, M, N, K, a, b, c, batch=(1, 1), alpha=1.0, inv_scale=None, bias=None,
              col_scale=None, residual=None, r=(0, 0, 0), C_pre=None, aux=None, act=ACT_NONE,
-             accumulate=False, reduce_batch=False, split_k=0):
+             accumulate=False, reduce_batch=False, split_k=0, a_dq=None, b_dq=None):
+        """a_dq / b_dq: device dequantisation factors of fp8 operands (quantize_fp8's state[1:2])."""
         g = _lib.GemmArgs()
         # grouped form: A / B / Cout / inv_scale given as lists of separately allocated tensors, one per b0 entry
         groups = [len(t) for t in (A, B, Cout, inv_scale) if isinstance(t, (list, tuple))]
@@ -192,7 +207,8 @@ class HipBackend:
                         tab[i] = _ptr(ti, True, bf16_ok=name != "inv_scale_group")
             A, B, Cout = (t[0] if isinstance(t, (list, tuple)) else t for t in (A, B, Cout))
             inv_scale = None
-        g.A, g.B, g.C = _ptr(A, bf16_ok=True), _ptr(B, bf16_ok=True), _ptr(Cout, bf16_ok=True)
+        g.A, g.B, g.C = _ptr(A, bf16_ok=True, fp8_ok=True), _ptr(B, bf16_ok=True, fp8_ok=True), _ptr(Cout, bf16_ok=True)
+        g.a_dq, g.b_dq = _ptr(a_dq, True), _ptr(b_dq, True)
         g.a_type, g.b_type, g.c_type, g.aux_type, g.r_type = _st(A), _st(B), _st(Cout), _st(aux), _st(residual)
         if C_pre is not None and C_pre.dtype != Cout.dtype:
             raise TypeError("gemm: C_pre must have C's storage type")
@@ -305,6 +321,25 @@ class HipBackend:
                       tuple(t.data_ptr() for pr in pairs for t in pr))
         plan.n_chunks = len(chunk_entry)
         return plan
+
+    # ---- fp8 (BASELINE config #5) ------------------------------------------------------
+    def quantize_fp8(self, x, q_dtype):
+        """Per-tensor scaled fp8 copy of a contiguous fp32 / bf16 tensor: returns (q, dq) with dq a device scalar
+        (amax / FP8_MAX) for calm_gemm's a_dq / b_dq."""
+        if not x.is_contiguous():
+            raise TypeError("quantize_fp8 expects a contiguous tensor")
+        q = torch.empty(x.shape, dtype=q_dtype, device=x.device)
+        state = torch.empty(2, dtype=torch.float32, device=x.device)
+        _lib.check(self.lib.calm_quantize_fp8(_ptr(x, bf16_ok=True), _st(x), x.numel(), q.data_ptr(), _st(q), _ptr(state),
+                                              _stream()), "calm_quantize_fp8")
+        return q, state[1:2]
+
+    def transpose_u8(self, x):
+        """[rows, cols] one-byte tensor -> its transpose [cols, rows] (contiguous)."""
+        rows, cols = x.shape
+        out = torch.empty(cols, rows, dtype=x.dtype, device=x.device)
+        _lib.check(self.lib.calm_transpose_u8(x.data_ptr(), out.data_ptr(), rows, cols, _stream()), "calm_transpose_u8")
+        return out
 
     def cast_bf16(self, src, dst):
         _lib.check(self.lib.calm_cast_bf16_one(_ptr(src), _ptr(dst, bf16_ok=True), src.numel(), _stream()),

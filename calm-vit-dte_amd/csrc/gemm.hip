@@ -46,9 +46,12 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
     if (!a || !a->A || !a->B || !a->C) return CALM_E_INVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch0 <= 0 || a->batch1 <= 0) return CALM_E_INVAL;
     if (a->dtype != CALM_F32 && a->dtype != CALM_BF16 && a->dtype != CALM_BF16X3) return CALM_E_UNSUPP;
-    for (int t : {a->a_type, a->b_type, a->c_type, a->aux_type, a->r_type})
+    for (int t : {a->c_type, a->aux_type, a->r_type})
         if (t != CALM_ST_F32 && t != CALM_ST_BF16) return CALM_E_INVAL;
-    const bool any_bf16_tensor = a->a_type || a->b_type || a->c_type || a->aux_type || a->r_type;
+    for (int t : {a->a_type, a->b_type})
+        if (t < CALM_ST_F32 || t > CALM_ST_FP8_E5M2) return CALM_E_INVAL;
+    const bool fp8 = a->a_type >= CALM_ST_FP8_E4M3 || a->b_type >= CALM_ST_FP8_E4M3;
+    const bool any_bf16_tensor = a->a_type || a->b_type || a->c_type || a->aux_type || a->r_type;      // (or fp8)
     if (any_bf16_tensor && a->dtype != CALM_BF16) return CALM_E_UNSUPP;       // bf16 tensors: bf16 matrix pipe only
     if (a->a_rs != 1 && a->a_cs != 1) return CALM_E_LAYOUT;
     if (a->b_rs != 1 && a->b_cs != 1) return CALM_E_LAYOUT;
@@ -70,6 +73,7 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
     GemmP p;
     p.A = a->A; p.B = a->B; p.C = a->C;
     p.a_type = a->a_type; p.b_type = a->b_type; p.c_type = a->c_type; p.aux_type = a->aux_type; p.r_type = a->r_type;
+    p.dq_a = fp8 ? a->a_dq : nullptr; p.dq_b = fp8 ? a->b_dq : nullptr;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.batch1 = a->batch1;
     p.a_rs = a->a_rs; p.a_cs = a->a_cs; p.a_b0 = a->a_b0; p.a_b1 = a->a_b1;
@@ -91,6 +95,25 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
     const int batch = a->batch0 * a->batch1;
     const bool akc = a->a_cs == 1;
     const bool bkc = a->b_cs == 1;
+    if (fp8) {
+        // fp8 family: both operands fp8 (B e4m3; A e4m3 or e5m2), k-contiguous, K and row strides multiples of 16 bytes,
+        // one launch per call (no k-split, no groups), dequantisation factors on the device
+        if (a->b_type != CALM_ST_FP8_E4M3 || a->a_type < CALM_ST_FP8_E4M3 || !a->a_dq || !a->b_dq) return CALM_E_INVAL;
+        if (a->dtype != CALM_BF16 || !akc || !bkc || a->n_group || a->reduce_batch || a->split_k > 1) return CALM_E_UNSUPP;
+        if ((a->K & 15) || (a->a_rs & 15) || (a->b_rs & 15) || (a->a_b0 & 15) || (a->a_b1 & 15) || (a->b_b0 & 15) ||
+            (a->b_b1 & 15) || !aligned16(a->A) || !aligned16(a->B))
+            return CALM_E_LAYOUT;
+        if (batch > 65535) return CALM_E_UNSUPP;
+        p.tiles_m = (a->M + WBM - 1) / WBM;
+        p.tiles_n = (a->N + WBN - 1) / WBN;
+        p.kpb = 0; p.kb_total = 0; p.kb_per_z = 0; p.atomic = 0; p.slices_per_batch = 0; p.reduce_group = 0;
+        p.ws = nullptr; p.ws_slice = 0;
+        if (query) {
+            *query = 0;
+            return 0;
+        }
+        return launch_fp8(p, dim3(p.tiles_m * p.tiles_n, batch), s);
+    }
     // 16-byte staging vectors hold 4 fp32 or 8 bf16 elements: sizes / strides of an operand must be multiples of that
     const int64_t ea = a->a_type == CALM_ST_BF16 ? 7 : 3, eb = a->b_type == CALM_ST_BF16 ? 7 : 3;
     auto mult = [](int64_t x, int64_t mask) { return (x & mask) == 0; };

@@ -52,6 +52,7 @@ struct GemmP {
     const void* Ag[4]; const void* Bg[4]; void* Cg[4]; const float* Sg[4];
     float* ws; long ws_slice;      // split launches with a workspace: slice blockIdx.y stores its partial tile at ws + y * ws_slice
     int a_type, b_type, c_type, aux_type, r_type;      // CALM_ST_*: only the bf16-operand family takes bf16 tensors
+    const float* dq_a; const float* dq_b;              // fp8 operands: device dequantisation factors (amax / FP8_MAX)
 };
 
 // operand base of batch entry (b0, b1); T = the operand's storage type
@@ -102,6 +103,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
                                               int r, int h, int z, int sgroup) {
     float scale = p.alpha;
     if (p.inv_scale) scale = scale / p.inv_scale[0];
+    if (TYPED && p.dq_a) scale *= p.dq_a[0] * p.dq_b[0];
     const int zc = (p.atomic && !p.slices_per_batch) ? 0 : z;
     const int cb0 = zc / p.batch1, cb1 = zc - cb0 * p.batch1;
     const long coff = cb0 * p.c_b0 + cb1 * p.c_b1;
@@ -202,5 +204,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmP& p, f32x16 (&acc)[MT][
 int launch_f32(const GemmP& p, dim3 grid, int bn, bool akc, bool bkc, bool vec, hipStream_t s);
 int launch_bf16(const GemmP& p, dim3 grid, int bn, bool akc, bool bkc, int npass, hipStream_t s);
 int launch_bf16_wide(const GemmP& p, dim3 grid, bool akc, bool bkc, hipStream_t s);
+int launch_fp8(const GemmP& p, dim3 grid, hipStream_t s);           // gemm_fp8.hip
 
 }  // namespace calm_gemm_detail

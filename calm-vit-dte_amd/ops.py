@@ -14,7 +14,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
-from .backend import ACT_GELU, ACT_GELU_BWD, ACT_NONE, act_dtype, bf16_pipeline, get_backend
+from .backend import ACT_GELU, ACT_GELU_BWD, ACT_NONE, act_dtype, bf16_pipeline, fp8_linears, get_backend
 from .spectral_norm import W16_ATTR
 
 # The reference calls the model under autocast(bfloat16) (distributed_trainer_cls.py:84): custom_fwd records the
@@ -138,6 +138,35 @@ def _sn_wbwd(be, G, w, u, v, sigma, ls=None, defer=False):
     return dW, d_ls
 
 
+E4M3, E5M2 = torch.float8_e4m3fn, torch.float8_e5m2
+
+
+def _fp8_ok(*dims):
+    """fp8 Linear products (backend.fp8_linears, BASELINE config #5): every contraction / row extent a multiple of 16."""
+    return fp8_linears() and all(d % 16 == 0 for d in dims)
+
+
+def _lin_fwd8(be, x2, w, sigma, out, **epi):
+    """_lin_fwd with both operands quantised to e4m3 (per-tensor scale, just in time)."""
+    M, K = x2.shape
+    N = w.shape[0]
+    xq, dqx = be.quantize_fp8(x2, E4M3)
+    wq, dqw = be.quantize_fp8(_c(w), E4M3)
+    be.gemm(xq, wq, out, M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), inv_scale=sigma, r=(N, 0, 0), split_k=1,
+            a_dq=dqx, b_dq=dqw, **epi)
+
+
+def _lin_dgrad8(be, dy2, w_eff, sigma, dx, **epi):
+    """dx = dy W / sigma with dy in e5m2 and a transposed e4m3 copy of the (effective) weight [N, K] -> [K, N]."""
+    M, N = dy2.shape
+    K = w_eff.shape[1]
+    dyq, dqd = be.quantize_fp8(dy2, E5M2)
+    wq, dqw = be.quantize_fp8(_c(w_eff), E4M3)
+    wtq = be.transpose_u8(wq)
+    be.gemm(dyq, wtq, dx, M, K, N, (N, 1, 0, 0), (N, 1, 0, 0), (K, 0, 0), inv_scale=sigma, r=(K, 0, 0), split_k=1,
+            a_dq=dqd, b_dq=dqw, **epi)
+
+
 CAST_GRADS = os.environ.get("CALM_CAST_GRADS", "1") != "0"      # A/B switch
 
 
@@ -249,8 +278,13 @@ class SNLinearFn(Function):
         out = torch.empty(x.shape[:-1] + (N,), dtype=act_dtype(N) if out16 else torch.float32, device=x.device)
         pre = torch.empty_like(out) if act == ACT_GELU else None
         res2 = _c(residual).reshape(-1, N) if residual is not None else None
-        _lin_fwd(be, x2, wop, sigma, out.view(-1, N), bias=bias, act=act, col_scale=ls, residual=res2,
-                 pre=pre.view(-1, N) if pre is not None else None)
+        ctx.fp8 = _fp8_ok(K, N) and x2.shape[0] >= 1024          # the large token-axis linears only
+        if ctx.fp8:
+            _lin_fwd8(be, x2, w, sigma, out.view(-1, N), bias=bias, act=act, col_scale=ls, residual=res2,
+                      C_pre=pre.view(-1, N) if pre is not None else None)
+        else:
+            _lin_fwd(be, x2, wop, sigma, out.view(-1, N), bias=bias, act=act, col_scale=ls, residual=res2,
+                     pre=pre.view(-1, N) if pre is not None else None)
         ctx.act = act
         ctx.wop = wop
         ctx.defer = _deferred(w)
@@ -281,11 +315,14 @@ class SNLinearFn(Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)                       # a bf16 input (LayerNorm output) gets a bf16 gradient
             if ls is not None:
-                wl = torch.empty_like(ctx.wop)
+                wl = torch.empty_like(w if ctx.fp8 else ctx.wop)
                 be.row_scale(w, ls, wl, N, K)
             else:
-                wl = ctx.wop
-            _lin_dgrad(be, dzg, wl, sigma, dx)
+                wl = w if ctx.fp8 else ctx.wop
+            if ctx.fp8:
+                _lin_dgrad8(be, dz, wl, sigma, dx)
+            else:
+                _lin_dgrad(be, dzg, wl, sigma, dx)
             dx = dx.view(ctx.xshape)
         db = _colsum(be, dz) if ctx.has_bias else None
         dres = dy if ctx.has_res else None
@@ -369,10 +406,15 @@ class MlpFn(Function):
         # hidden state and pre-activation feed GEMMs / the GELU' epilogue only: bf16 tensors in the bf16 pipeline
         hp = torch.empty(M, Hd, dtype=act_dtype(Hd), device=x.device)
         hg = torch.empty_like(hp)
-        _lin_fwd(be, x2, wop1, s1, hg, bias=b1, act=ACT_GELU, pre=hp)
         out = torch.empty(x.shape[:-1] + (N,), dtype=torch.float32, device=x.device)
         res2 = _c(residual).reshape(-1, N) if residual is not None else None
-        _lin_fwd(be, hg, wop2, s2, out.view(-1, N), bias=b2, col_scale=ls, residual=res2)
+        ctx.fp8 = _fp8_ok(K, Hd, N)
+        if ctx.fp8:                      # both products on fp8 operands; hidden state / pre-activation stay bf16 tensors
+            _lin_fwd8(be, x2, w1, s1, hg, bias=b1, act=ACT_GELU, C_pre=hp)
+            _lin_fwd8(be, hg, w2, s2, out.view(-1, N), bias=b2, col_scale=ls, residual=res2)
+        else:
+            _lin_fwd(be, x2, wop1, s1, hg, bias=b1, act=ACT_GELU, pre=hp)
+            _lin_fwd(be, hg, wop2, s2, out.view(-1, N), bias=b2, col_scale=ls, residual=res2)
         ctx.wops = (wop1, wop2)
         ctx.has_b1, ctx.has_b2, ctx.has_res = b1 is not None, b2 is not None, residual is not None
         ctx.defer = (_deferred(w1), _deferred(w2))
@@ -396,12 +438,15 @@ class MlpFn(Function):
         db2 = _colsum(be, do2) if ctx.has_b2 else None
         wop1, wop2 = ctx.wops
         if ls is not None:
-            w2l = torch.empty_like(wop2)
+            w2l = torch.empty_like(w2 if ctx.fp8 else wop2)
             be.row_scale(w2, ls, w2l, N, Hd)
         else:
-            w2l = wop2
+            w2l = w2 if ctx.fp8 else wop2
         dhp = torch.empty_like(hp)
-        _lin_dgrad(be, do2g, w2l, s2, dhp, act=ACT_GELU_BWD, aux=hp)
+        if ctx.fp8:
+            _lin_dgrad8(be, do2, w2l, s2, dhp, act=ACT_GELU_BWD, aux=hp)
+        else:
+            _lin_dgrad(be, do2g, w2l, s2, dhp, act=ACT_GELU_BWD, aux=hp)
         G1 = _zeros_big(w1.shape, w1)
         _lin_wgrad(be, dhp, x2, G1)
         dW1, _ = _sn_wbwd(be, G1, w1, u1, v1, s1, defer=ctx.defer[0])
@@ -409,7 +454,10 @@ class MlpFn(Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x2)
-            _lin_dgrad(be, dhp, wop1, s1, dx)
+            if ctx.fp8:
+                _lin_dgrad8(be, dhp, w1, s1, dx)
+            else:
+                _lin_dgrad(be, dhp, wop1, s1, dx)
             dx = dx.view(ctx.xshape)
         dres = dout if ctx.has_res else None
         return dx, dW1, db1, dW2, db2, d_ls, dres, None, None, None, None, None, None

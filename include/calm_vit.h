@@ -38,7 +38,8 @@ extern "C" {
  *   CALM_BF16   operands rounded to bf16 in LDS, fp32 accumulate (what autocast(bfloat16) computes)
  *   CALM_BF16X3 operands split hi+lo bf16, 3 MFMA passes, fp32 accumulate: ~2^-17 relative product error */
 enum { CALM_F32 = 0, CALM_BF16 = 1, CALM_BF16X3 = 2 };
-enum { CALM_ST_F32 = 0, CALM_ST_BF16 = 1 };          /* storage type of a tensor in HBM */
+enum { CALM_ST_F32 = 0, CALM_ST_BF16 = 1, CALM_ST_FP8_E4M3 = 2, CALM_ST_FP8_E5M2 = 3 };   /* storage type of a tensor in HBM
+                                                          (fp8: OCP e4m3fn / e5m2 as gfx950 implements them) */
 enum { CALM_ACT_NONE = 0, CALM_ACT_GELU = 1, CALM_ACT_GELU_BWD = 2 };
 
 int         calm_abi_version(void);
@@ -112,6 +113,11 @@ typedef struct calm_gemm_args {
      * Split / batch-reduced outputs (fp32 atomics or workspace) must be fp32. */
     int32_t      a_type, b_type, c_type, aux_type, r_type;
     int32_t      reserved_;
+    /* fp8 operands (BASELINE configs[4], "bf16 + fp8 MFMA GEMMs"): a_type in {FP8_E4M3, FP8_E5M2}, b_type FP8_E4M3, both
+     * k-contiguous with K and row strides multiples of 16, dtype == CALM_BF16, no groups / k-split; a_dq / b_dq are the
+     * DEVICE dequantisation factors written by calm_quantize_fp8 (amax / FP8_MAX): the epilogue multiplies the fp32
+     * accumulator by a_dq * b_dq before alpha, sigma, bias ...  Products run on v_mfma_f32_32x32x16_{fp8,bf8}_fp8. */
+    const float* a_dq; const float* b_dq;
 } calm_gemm_args;
 #define CALM_GEMM_MAX_GROUP 4
 
@@ -277,6 +283,12 @@ typedef struct calm_cast_entry {
 } calm_cast_entry;
 int32_t calm_cast_chunk_elems(void);
 int calm_cast_bf16(const calm_cast_entry* entries_dev, const int32_t* chunk_entry_dev, int32_t n_chunks, void* stream);
+/* Per-tensor fp8 quantisation (ABI v4): q[i] = fp8(x[i] * FP8_MAX / amax(|x|)) with FP8_MAX = 448 (e4m3) / 57344 (e5m2),
+ * state[0] <- amax, state[1] <- amax / FP8_MAX (the dequantisation factor calm_gemm takes as a_dq / b_dq); x fp32 or
+ * bf16, n % 4 == 0.  Two launches (amax, then convert: just-in-time scaling, no history).
+ * calm_transpose_u8: out[c][r] = in[r][c] on bytes — the transposed fp8 weight copy of the input-gradient product. */
+int calm_quantize_fp8(const void* x, int32_t x_type, int64_t n, void* q, int32_t q_type, float* state, void* stream);
+int calm_transpose_u8(const void* in, void* out, int32_t rows, int32_t cols, void* stream);
 /* one tensor: dst[i] = bf16(src[i]) — the fp32 residual-stream gradient that two backward GEMMs are about to read */
 int calm_cast_bf16_one(const float* src, void* dst, int64_t n, void* stream);
 

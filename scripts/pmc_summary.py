@@ -42,11 +42,14 @@ with open(out, "w") as f:
     for gui, k, n, util, rd, wr, t, c in rows:
         bw = (rd + wr) / t / 1e9 if t else 0.0
         f.write(f"\"{k}\",{n},{gui:.0f},{c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0):.0f},{util:.4f},{rd:.0f},{wr:.0f},{t:.6f},{bw:.1f}\n")
-for gui, k, n, util, rd, wr, t, c in rows[:16]:
-    print(f"{k[:58]:58s} n={n:5d} mfma_util={100*util:5.1f}%  rd={rd/1e9:8.2f}GB wr={wr/1e9:8.2f}GB t={1e3*t:8.2f}ms")
-
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 stamp = {os.path.basename(f): hashlib.sha256(open(f, "rb").read()).hexdigest()
          for f in sorted(glob.glob(os.path.join(root, "calm-vit-dte_amd", "csrc", "*")))}
 with open(out + ".stamp.json", "w") as f:
     json.dump({"sources_sha256": stamp, "argv": sys.argv[1:]}, f, indent=1, sort_keys=True)
+
+try:
+    for gui, k, n, util, rd, wr, t, c in rows[:16]:
+        print(f"{k[:58]:58s} n={n:5d} mfma_util={100*util:5.1f}%  rd={rd/1e9:8.2f}GB wr={wr/1e9:8.2f}GB t={1e3*t:8.2f}ms")
+except BrokenPipeError:
+    pass

@@ -38,9 +38,23 @@ class EmulatedBackend:
         import calm_vit_dte_amd as calm
         return calm.backend.effective_precision()
 
+    # ---- fp8: per-tensor scaled OCP fp8 copies (torch's float8 dtypes round to nearest even like v_cvt_pk_fp8_f32) ----
+    def quantize_fp8(self, x, q_dtype):
+        fmax = 448.0 if q_dtype == torch.float8_e4m3fn else 57344.0
+        amax = x.float().abs().max()
+        sc = fmax / amax if amax > 0 else torch.tensor(1.0)
+        q = (x.float() * sc).clamp(-fmax, fmax).to(q_dtype)
+        return q, (amax / fmax if amax > 0 else torch.tensor(1.0)).reshape(1).float()
+
+    def transpose_u8(self, x):
+        return x.t().contiguous()
+
     def gemm(self, A, B, Cout, M, N, K, a, b, c, batch=(1, 1), alpha=1.0, inv_scale=None, bias=None,
              col_scale=None, residual=None, r=(0, 0, 0), C_pre=None, aux=None, act=ACT_NONE,
-             accumulate=False, reduce_batch=False, split_k=0):
+             accumulate=False, reduce_batch=False, split_k=0, a_dq=None, b_dq=None):
+        if a_dq is not None:                                # fp8 operands: exact in fp32; the factors join alpha
+            A, B = A.float(), B.float()
+            alpha = alpha * float(a_dq) * float(b_dq)
         lists = [t for t in (A, B, Cout, inv_scale) if isinstance(t, (list, tuple))]
         if lists:                                           # grouped form (include/calm_vit.h)
             n = len(lists[0])

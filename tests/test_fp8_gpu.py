@@ -1,0 +1,102 @@
+"""BASELINE config #5 ("bf16 + fp8 MFMA GEMMs"): the fp8 kernel family of calm_gemm (v_mfma_f32_32x32x16_fp8_fp8 /
+_bf8_fp8, OCP e4m3fn / e5m2 operands with one scale per tensor) and the per-tensor quantisers, through the C-ABI against
+the emulation of exactly their arithmetic (torch float8 dtypes), and the Large-224 model with its Linear layers'
+forward / input-gradient products in fp8 against the reference fixture within a stated fp8-level tolerance."""
+import pytest
+import torch
+
+import calm_vit_dte_amd as calm
+import weights as W
+from emulated_backend import EmulatedBackend
+from helpers import CONFIGS, load_golden, rel_err
+from test_host_logic_cpu import build_model
+
+pytestmark = pytest.mark.gpu
+E4M3, E5M2 = torch.float8_e4m3fn, torch.float8_e5m2
+FP8_VS_FP32_Y, FP8_VS_FP32_DX = 6e-2, 1.5e-1      # e4m3 has 3 mantissa bits, e5m2 (gradients) 2: stated, measured ~2e-2 / 6e-2
+
+
+@pytest.fixture(autouse=True)
+def _restore():
+    yield
+    calm.backend.set_matmul_precision("fp32")
+    calm.ops.set_noise_override(None)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+@pytest.mark.parametrize("dtype", [E4M3, E5M2])
+@pytest.mark.parametrize("src", [torch.float32, torch.bfloat16])
+def test_quantize_fp8_matches_emulation(dtype, src):
+    hip, emu = calm.backend.get_backend(), EmulatedBackend()
+    x = (rnd(777, 96, seed=1) * torch.linspace(0.01, 30.0, 96)).to(src)
+    q_ref, dq_ref = emu.quantize_fp8(x, dtype)
+    q_hip, dq_hip = hip.quantize_fp8(x.cuda(), dtype)
+    assert abs(float(dq_hip) - float(dq_ref)) <= 1e-6 * float(dq_ref)
+    same = (q_hip.cpu().view(torch.uint8) == q_ref.view(torch.uint8)).float().mean()
+    assert same > 0.999, float(same)                          # identical up to ties of the scaled product
+    assert rel_err(q_hip.float().cpu() * float(dq_hip), x.float()) < (0.07 if dtype == E4M3 else 0.13)
+    t = hip.transpose_u8(q_hip[:64])
+    assert torch.equal(t.cpu().view(torch.uint8), q_hip[:64].cpu().view(torch.uint8).t().contiguous())
+
+
+FP8_CASES = [
+    # M, N, K, batch, A dtype
+    (512, 256, 128, (1, 1), E4M3),
+    (3000, 1344, 672, (1, 1), E4M3),          # MLP forward
+    (3000, 672, 1344, (1, 1), E5M2),          # MLP input gradient (e5m2 gradient operand)
+    (260, 136, 80, (1, 1), E4M3),             # ragged M, N; K not a multiple of the 64-deep k-tile
+    (200, 100, 144, (2, 3), E5M2),            # batched
+    (57, 24, 16, (1, 1), E4M3),
+]
+
+
+@pytest.mark.parametrize("M,N,K,batch,adt", FP8_CASES)
+@pytest.mark.parametrize("epi", ["plain", "full"])
+def test_fp8_gemm_matches_emulation(M, N, K, batch, adt, epi):
+    hip, emu = calm.backend.get_backend(), EmulatedBackend()
+    b0, b1 = batch
+    calm.backend.set_matmul_precision("fp8")
+    A32, B32 = rnd(b0, b1, M, K, seed=1), rnd(b0, b1, N, K, seed=2, scale=0.1)
+    Aq, dqa = emu.quantize_fp8(A32, adt)
+    Bq, dqb = emu.quantize_fp8(B32, E4M3)
+    a, b, c = (K, 1, b1 * M * K, M * K), (K, 1, b1 * N * K, N * K), (N, b1 * M * N, M * N)
+    kw, cdt, tol = {}, torch.float32, 1e-4
+    if epi == "full":
+        kw = dict(alpha=0.5, inv_scale=torch.tensor([1.3]), bias=rnd(N, seed=3), col_scale=rnd(N, seed=4),
+                  residual=rnd(b0, b1, M, N, seed=5), r=c, act=2, aux=rnd(b0, b1, M, N, seed=6).bfloat16())
+        cdt, tol = torch.bfloat16, 6e-3
+    kw_hip = {k: (v.cuda() if torch.is_tensor(v) else v) for k, v in kw.items()}
+    C_ref = torch.zeros(b0, b1, M, N, dtype=cdt)
+    C_hip = torch.full((b0, b1, M, N), 7.0, dtype=cdt).cuda()
+    emu.gemm(Aq, Bq, C_ref, M, N, K, a, b, c, batch=batch, split_k=1, a_dq=dqa, b_dq=dqb, **kw)
+    hip.gemm(Aq.cuda(), Bq.cuda(), C_hip, M, N, K, a, b, c, batch=batch, split_k=1, a_dq=dqa.cuda(), b_dq=dqb.cuda(), **kw_hip)
+    assert rel_err(C_hip.float(), C_ref.float()) < tol
+    # and the quantised product is the fp32 product to fp8 accuracy
+    if epi == "plain":
+        exact = torch.matmul(A32, B32.transpose(-1, -2))
+        assert rel_err(C_hip.float(), exact) < (0.05 if adt == E4M3 else 0.1)
+
+
+def test_large224_with_fp8_linears_within_stated_tolerance_of_reference_fixture():
+    name = "large224_cls"
+    g = load_golden(name + "_b1")
+    cfg = CONFIGS[name]
+    S = cfg.seq_length
+    calm.backend.set_matmul_precision("fp8")
+    m = build_model(name, g, "cuda").train()
+    x = torch.from_numpy(W.make_input((1, 3, S, S), 2)).cuda().requires_grad_(True)
+    calm.ops.set_noise_override(W.NoiseStream(7))
+    y, kl = m(x)
+    gy = torch.from_numpy(W.make_input(tuple(y.shape), 3, "gy")).cuda()
+    ((y * gy).sum() + 0.5 * kl).backward()
+    calm.ops.set_noise_override(None)
+    assert torch.isfinite(y).all() and torch.isfinite(x.grad).all()
+    ey, edx = rel_err(y.detach(), g["train/y"]), rel_err(x.grad, g["train/dx"])
+    print(f"\n[large224 fp8] y {ey:.2e} dx {edx:.2e}")
+    assert ey < FP8_VS_FP32_Y and edx < FP8_VS_FP32_DX
+    ref = float((torch.tensor(g["train/grad_norms"]).double() ** 2).sum()) ** 0.5
+    got = sum(float(p.grad.double().pow(2).sum()) for p in m.parameters()) ** 0.5
+    assert abs(got - ref) < 2e-2 * ref
