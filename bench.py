@@ -53,6 +53,9 @@ PRECISION_INFO = {
     "fp32": ("f32", PEAK_FP32_MATRIX_TFLOPS, "gemm_f32_kernel (calm_gemm, v_mfma_f32_32x32x2_f32)"),
     "bf16": ("bf16 (bf16 GEMM / attention tensors, f32 accumulate, f32 residual stream and parameters)",
              PEAK_BF16_DENSE_TFLOPS, "gemm_bf16w_kernel / gemm_bf16c_kernel (calm_gemm, v_mfma_f32_32x32x16_bf16)"),
+    "fp8": ("bf16 + fp8 (e4m3 / e5m2 operands of the Linear forward and input-gradient GEMMs, f32 accumulate; bf16 "
+            "pipeline elsewhere)", PEAK_BF16_DENSE_TFLOPS,
+            "gemm_fp8w_kernel + gemm_bf16w/c_kernel (calm_gemm; non-scaled fp8 MFMAs run at the bf16 rate)"),
     "bf16x3": ("f32 via bf16x3 split", PEAK_BF16_DENSE_TFLOPS / 3.0,
                "gemm_bf16c_kernel<3> (calm_gemm, 3 x v_mfma_f32_32x32x16_bf16 per product)"),
 }
@@ -267,9 +270,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="small224", choices=list(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "bf16x3", "fp8"],
                     help="matrix pipe of the GEMMs (tensors stay fp32): exact fp32 MFMA (default, config #2), "
-                         "bf16 operands (autocast arithmetic, configs #3-5), or the fp32-accurate bf16x3 split")
+                         "bf16 operands (autocast arithmetic, configs #3-5), the fp32-accurate bf16x3 split, or fp8: "
+                         "the bf16 pipeline with fp8 Linear forward / input-gradient GEMMs (config #5)")
     ap.add_argument("--prof-steps", type=int, default=1)
     ap.add_argument("--graph", action="store_true", help="capture the whole step into a hipGraph (N=1 only)")
     ap.add_argument("--torch-optim", action="store_true",
@@ -298,7 +302,8 @@ def main():
     batch = args.batch or wl["batch"]
     S, classes = wl["kw"]["seq_length"], wl["kw"]["out_features"]
 
-    calm.backend.set_matmul_precision("fp32" if args.autocast else args.precision)
+    # under --autocast the region selects the bf16 pipeline itself; a global 'fp8' adds the fp8 Linear products to it
+    calm.backend.set_matmul_precision(("fp8" if args.precision == "fp8" else "fp32") if args.autocast else args.precision)
     model = build_model(calm, wl["kw"], device).train()
     trainer.sync_module_states(model)
     x, y = synthetic_batch(batch, S, classes, seed=rank, device=device)     # resident in HBM before timing
@@ -312,7 +317,8 @@ def main():
         opt = trainer.make_optimizer(model) if args.torch_optim else trainer.FusedClipAdamW(model)
         reducer = trainer.BucketedGradReducer(model) if world > 1 else None
         if args.autocast:
-            args.precision = "bf16"                         # what the autocast region selects; labels the JSON line
+            if args.precision != "fp8":
+                args.precision = "bf16"                     # what the autocast region selects; labels the JSON line
             step = trainer.TrainStep(model, opt, reducer, scaler=torch.amp.GradScaler("cuda"),
                                      autocast_dtype=torch.bfloat16)
         else:
@@ -365,7 +371,7 @@ def main():
                         "gemm_ms_per_step": round(ms / args.prof_steps, 2),
                         "algorithmic_gflop_per_step": round(flops / args.prof_steps / 1e9, 1)}
             # HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate passes) from the committed summary
-            detail = pmc_traffic("gemm_f32_kernel" if args.precision == "fp32" else "gemm_bf16")
+            detail = pmc_traffic("gemm_f32_kernel" if args.precision == "fp32" else "calm_gemm_detail::gemm_bf16")
             if detail is not None:
                 roofline["traffic"] = detail["hbm_bytes_per_launch"]
                 roofline["traffic_detail"] = detail

@@ -77,7 +77,7 @@ def test_fp8_gemm_matches_emulation(M, N, K, batch, adt, epi):
     # and the quantised product is the fp32 product to fp8 accuracy
     if epi == "plain":
         exact = torch.matmul(A32, B32.transpose(-1, -2))
-        assert rel_err(C_hip.float(), exact) < (0.05 if adt == E4M3 else 0.1)
+        assert rel_err(C_hip.float(), exact) < (0.08 if adt == E4M3 else 0.15)
 
 
 def test_large224_with_fp8_linears_within_stated_tolerance_of_reference_fixture():
