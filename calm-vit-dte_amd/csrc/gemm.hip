@@ -92,6 +92,15 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
         p.Cg[g] = on ? a->C_group[g] : nullptr;
         p.Sg[g] = on ? a->inv_scale_group[g] : nullptr;
     }
+    {   // vector epilogue: every tensor the epilogue touches addressable in aligned groups of 4 columns
+        auto m4 = [](int64_t x) { return (x & 3) == 0; };
+        bool ev = m4(a->N) && m4(a->c_rs) && m4(a->c_b0) && m4(a->c_b1) && aligned16(a->C) &&
+                  (!a->C_pre || aligned16(a->C_pre)) && (!a->aux || aligned16(a->aux)) &&
+                  (!a->bias || aligned16(a->bias)) && (!a->col_scale || aligned16(a->col_scale)) &&
+                  (!a->residual || (aligned16(a->residual) && m4(a->r_rs) && m4(a->r_b0) && m4(a->r_b1)));
+        for (int g = 0; g < a->n_group; ++g) ev = ev && (!a->C_group[g] || aligned16(a->C_group[g]));
+        p.epi_vec = ev && CALM_GEMM_VEC_EPILOGUE;
+    }
     const int batch = a->batch0 * a->batch1;
     const bool akc = a->a_cs == 1;
     const bool bkc = a->b_cs == 1;

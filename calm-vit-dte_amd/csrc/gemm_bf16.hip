@@ -239,7 +239,9 @@ __global__ __launch_bounds__(NTHREADS, NPASS == 3 ? 2 : CALM_GEMM_BF16_WAVES) vo
     };
     if (p.K % CK == 0) k_loop(std::true_type{});
     else k_loop(std::false_type{});
-    gemm_epilogue<MT, NT, true>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
+    static_assert(sizeof(lds) >= 4096 * (NTHREADS / 64), "the epilogue's per-wave scratch lives in the operand stages");
+    gemm_epilogue<MT, NT, true>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb,
+                                (lds_float*)(&lds[0][0][0][0]) + 1024 * wave);
 }
 
 // ---- wide tile of the bf16-operand family: 256x128x32 per 512-thread workgroup (8 waves as 4x2, each 64x64) ----
@@ -285,14 +287,19 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
 
     typedef TCursor<TA, AKC, WBM, WBM, WTHREADS, MC_LDW> CurA;
     typedef TCursor<TB, BKC, WBN, WBN, WTHREADS, MC_LD> CurB;
+    // The kernel is bound by the latency of its global loads (bytes in flight per CU), not by the matrix pipe: bf16
+    // tensors need only 12 staging registers per k-tile, so TWO k-tiles are kept in flight (register sets 0/1,
+    // prefetch distance 2); fp32 tensors (24 registers per k-tile) keep distance 1 to stay within 128 VGPRs.
+    constexpr int NSET = (sizeof(TA) == 2 && sizeof(TB) == 2 && CALM_GEMM_BF16_DEEP) ? 2 : 1;
     CurA ca;
     CurB cb;
-    typename CurA::vec_t ra[CurA::NV];
-    typename CurB::vec_t rb[CurB::NV];
+    typename CurA::vec_t ra[NSET][CurA::NV];
+    typename CurB::vec_t rb[NSET][CurB::NV];
     auto k_loop = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     int cur_b = -1;
-    auto fetch = [&](int kb) {
+    auto fetch = [&](int kb, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
         const int b = p.kb_total == p.kpb ? 0 : kb / p.kpb;
         const int k0 = (kb - b * p.kpb) * CK;
         if (b != cur_b) {
@@ -301,22 +308,31 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
             cb.init(operand_base<TB>(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
             cur_b = b;
         }
-        ca.template load<FULL>(p.K - k0, ra);
-        cb.template load<FULL>(p.K - k0, rb);
+        ca.template load<FULL>(p.K - k0, ra[SET]);
+        cb.template load<FULL>(p.K - k0, rb[SET]);
     };
+    auto stash = [&](int st, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        ca.template store<1>(lds_a[st], lds_a[st], ra[SET]);
+        cb.template store<1>(lds_b[st], lds_b[st], rb[SET]);
+    };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, NSET - 1> S1;
 
     int buf = 0;
     if (kb_begin < kb_end) {
-        fetch(kb_begin);
-        ca.template store<1>(lds_a[0], lds_a[0], ra);
-        cb.template store<1>(lds_b[0], lds_b[0], rb);
+        fetch(kb_begin, S0{});
+        stash(0, S0{});
     }
+    if constexpr (NSET == 2)
+        if (kb_begin + 1 < kb_end) fetch(kb_begin + 1, S1{});
     __syncthreads();
 
-    for (int kb = kb_begin; kb < kb_end; ++kb) {
-        const bool more = kb + 1 < kb_end;
+    // one k-tile: issue the loads of tile kb+NSET into register set FAR, multiply tile kb out of LDS stage `buf`,
+    // move tile kb+1 (register set NEAR: loaded a whole iteration ago when NSET == 2) into the other stage
+    auto iteration = [&](int kb, auto near_tag, auto far_tag) {
         if (p.reduce_group && kb != kb_begin && kb % p.kpb == 0) group_rescale<MT, NT>(p, acc, kb / p.kpb);
-        if (more) fetch(kb + 1);
+        if (kb + NSET < kb_end) fetch(kb + NSET, far_tag);
 #pragma unroll
         for (int s = 0; s < CK / 16; ++s) {
             bf16x8 af[MT], bf[NT];
@@ -330,17 +346,24 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (more) {
-            ca.template store<1>(lds_a[buf ^ 1], lds_a[buf ^ 1], ra);
-            cb.template store<1>(lds_b[buf ^ 1], lds_b[buf ^ 1], rb);
-        }
+        if (kb + 1 < kb_end) stash(buf ^ 1, near_tag);
         __syncthreads();
         buf ^= 1;
+    };
+    if constexpr (NSET == 2) {
+        for (int kb = kb_begin; kb < kb_end; kb += 2) {
+            iteration(kb, S1{}, S0{});
+            if (kb + 1 < kb_end) iteration(kb + 1, S0{}, S1{});
+        }
+    } else {
+        for (int kb = kb_begin; kb < kb_end; ++kb) iteration(kb, S0{}, S0{});
     }
     };
     if (p.K % CK == 0) k_loop(std::true_type{});
     else k_loop(std::false_type{});
-    gemm_epilogue<MT, NT, true>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
+    static_assert(sizeof(lds_a) >= 4096 * (WTHREADS / 64), "the epilogue's per-wave scratch lives in the A stages");
+    gemm_epilogue<MT, NT, true>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb,
+                                (lds_float*)(&lds_a[0][0]) + 1024 * wave);
 }
 
 // ---- launchers: operand storage types (fp32 / bf16 in HBM) x operand layouts -----------------------------------------

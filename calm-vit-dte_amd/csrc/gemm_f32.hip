@@ -283,7 +283,8 @@ __global__ __launch_bounds__(NTHREADS, BN_ == 96 ? CALM_GEMM_WAVES96 : CALM_GEMM
     // (a peeled loop without the per-iteration decisions for single-entry, whole-k-block launches measured +2% on
     // forward / input-gradient shapes, -2% on weight gradients and -0.6% on the training step: not kept)
 
-    gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb);
+    static_assert(sizeof(As) >= 4096 * (NTHREADS / 64), "the epilogue's per-wave scratch lives in the A stages");
+    gemm_epilogue<MT, NT>(p, acc, m0, n0, wm, wn, r, h, z, (kb_end - 1) / p.kpb, (lds_float*)(&As[0][0][0]) + 1024 * wave);
 }
 
 template <bool AKC, bool BKC, int VEC>

@@ -125,7 +125,8 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_fp8w_kernel(const GemmP p) {
         __syncthreads();
         buf ^= 1;
     }
-    gemm_epilogue<MT, NT, true>(p, acc, m0, n0, wm, wn, r, h, z, 0);
+    static_assert(sizeof(lds_a) >= 4096 * (WTHREADS / 64), "the epilogue's per-wave scratch lives in the A stages");
+    gemm_epilogue<MT, NT, true>(p, acc, m0, n0, wm, wn, r, h, z, 0, (lds_float*)(&lds_a[0][0]) + 1024 * wave);
 }
 
 int launch_fp8(const GemmP& p, dim3 grid, hipStream_t s) {
