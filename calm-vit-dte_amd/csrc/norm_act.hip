@@ -279,6 +279,12 @@ __global__ __launch_bounds__(NT) void rope_fwd_kernel(const void* __restrict__ c
 }
 
 constexpr int ROPE_MAX_HALF = 256;
+#ifndef CALM_ROPE_VEC
+#define CALM_ROPE_VEC 1        // 0: always the one-element kernels (A/B runs)
+#endif
+#ifndef CALM_ROPE_BWD_GRID
+#define CALM_ROPE_BWD_GRID 1024
+#endif
 
 __global__ __launch_bounds__(NT) void rope_bwd_kernel(const void* __restrict__ d_out, const void* __restrict__ xr,
                                                       const float* __restrict__ table, void* __restrict__ d_content,
@@ -314,6 +320,99 @@ __global__ __launch_bounds__(NT) void rope_bwd_kernel(const void* __restrict__ d
     }
     __syncthreads();
     for (int j = threadIdx.x; j < half; j += NT) atomicAdd(d_inv_freq + j, facc[j]);
+}
+
+// ---- two-element form (dc and dr/2 even; every shape of the model except the dr = 22 / 10 stages of reduce blocks) ----
+// The one-element kernels above cost a 64-bit division per element and, on bf16 tensors, 2-byte accesses: at the HBM
+// roofline on fp32 tensors, 2-3x off it on bf16 ones.  Here a thread owns a fixed pair of columns (so the angle
+// gradient accumulates in registers) and walks rows: 4-byte (bf16) / 8-byte (fp32) accesses, one 32-bit division per
+// row for the position, whole rows contiguous per workgroup pass.
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2_t ldt2(const void* p, long i, int type) {
+    if (type == CALM_ST_BF16) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        const bf16x2_t b = *reinterpret_cast<const bf16x2_t*>(reinterpret_cast<const __bf16*>(p) + i);
+        return f32x2_t{(float)b[0], (float)b[1]};
+    }
+    return *reinterpret_cast<const f32x2_t*>(reinterpret_cast<const float*>(p) + i);
+}
+__device__ __forceinline__ void stt2(void* p, long i, f32x2_t v, int type) {
+    if (type == CALM_ST_BF16) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<bf16x2_t*>(reinterpret_cast<__bf16*>(p) + i) = bf16x2_t{(__bf16)v[0], (__bf16)v[1]};
+    } else {
+        *reinterpret_cast<f32x2_t*>(reinterpret_cast<float*>(p) + i) = v;
+    }
+}
+
+__global__ __launch_bounds__(NT) void rope_fwd_vec_kernel(const void* __restrict__ content, const void* __restrict__ xr,
+                                                          const float* __restrict__ table, void* __restrict__ out,
+                                                          int nrows, int S, int H, int dc, int dr, int content_type,
+                                                          int xr_type, int out_type) {
+    const int half = dr >> 1, ic = dc >> 1, ipr = ic + (half >> 1);     // items (column pairs) per row
+    const int rpb = NT / ipr;                                            // rows per workgroup pass
+    const int r_in = threadIdx.x / ipr, j = threadIdx.x - r_in * ipr;
+    if (r_in >= rpb) return;
+    const float* cosT = table;
+    const float* sinT = table + (long)S * half;
+#pragma unroll 2
+    for (int row = blockIdx.x * rpb + r_in; row < nrows; row += gridDim.x * rpb) {
+        const long o = (long)row * (dc + dr);
+        if (j < ic) {
+            stt2(out, o + 2 * j, ldt2(content, (long)row * dc + 2 * j, content_type), out_type);
+        } else {
+            const int jj = 2 * (j - ic);
+            const int s = (row / H) % S;
+            const f32x2_t c = *reinterpret_cast<const f32x2_t*>(cosT + s * half + jj);
+            const f32x2_t sn = *reinterpret_cast<const f32x2_t*>(sinT + s * half + jj);
+            const f32x2_t x1 = ldt2(xr, (long)row * dr + jj, xr_type), x2 = ldt2(xr, (long)row * dr + jj + half, xr_type);
+            stt2(out, o + dc + jj, x1 * c - x2 * sn, out_type);
+            stt2(out, o + dc + jj + half, x2 * c + x1 * sn, out_type);
+        }
+    }
+}
+
+__global__ __launch_bounds__(NT) void rope_bwd_vec_kernel(const void* __restrict__ d_out, const void* __restrict__ xr,
+                                                          const float* __restrict__ table, void* __restrict__ d_content,
+                                                          void* __restrict__ d_xr, float* __restrict__ d_inv_freq,
+                                                          int nrows, int S, int H, int dc, int dr, int dout_type,
+                                                          int xr_type, int dcontent_type, int dxr_type) {
+    __shared__ float facc[ROPE_MAX_HALF];
+    const int half = dr >> 1, ic = dc >> 1, ipr = ic + (half >> 1);
+    for (int k = threadIdx.x; k < half; k += NT) facc[k] = 0.f;
+    __syncthreads();
+    const int rpb = NT / ipr;
+    const int r_in = threadIdx.x / ipr, j = threadIdx.x - r_in * ipr;
+    const float* cosT = table;
+    const float* sinT = table + (long)S * half;
+    const bool rot = r_in < rpb && j >= ic;
+    const int jj = 2 * (j - ic);
+    f32x2_t acc = {0.f, 0.f};
+    if (r_in < rpb) {
+#pragma unroll 2
+        for (int row = blockIdx.x * rpb + r_in; row < nrows; row += gridDim.x * rpb) {
+            const long go = (long)row * (dc + dr);
+            if (j < ic) {
+                stt2(d_content, (long)row * dc + 2 * j, ldt2(d_out, go + 2 * j, dout_type), dcontent_type);
+            } else {
+                const int s = (row / H) % S;
+                const f32x2_t c = *reinterpret_cast<const f32x2_t*>(cosT + s * half + jj);
+                const f32x2_t sn = *reinterpret_cast<const f32x2_t*>(sinT + s * half + jj);
+                const f32x2_t g1 = ldt2(d_out, go + dc + jj, dout_type), g2 = ldt2(d_out, go + dc + jj + half, dout_type);
+                const f32x2_t x1 = ldt2(xr, (long)row * dr + jj, xr_type), x2 = ldt2(xr, (long)row * dr + jj + half, xr_type);
+                stt2(d_xr, (long)row * dr + jj, g1 * c + g2 * sn, dxr_type);
+                stt2(d_xr, (long)row * dr + jj + half, g2 * c - g1 * sn, dxr_type);
+                const f32x2_t dang = g1 * (-x1 * sn - x2 * c) + g2 * (-x2 * sn + x1 * c);
+                acc += dang * (float)s;
+            }
+        }
+    }
+    if (rot) {
+        atomicAdd(&facc[jj], acc[0]);
+        atomicAdd(&facc[jj + 1], acc[1]);
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < half; k += NT) atomicAdd(d_inv_freq + k, facc[k]);
 }
 
 // ------------------------------------------------------------------ softmax (one wave per row)
@@ -670,6 +769,16 @@ int calm_layernorm_bwd(const void* dy, const float* x, const float* w, const flo
 }
 
 static bool st_ok(int t) { return t == CALM_ST_F32 || t == CALM_ST_BF16; }
+// two-element RoPE kernels: column pairs must not straddle the content / first-half / second-half boundaries
+static bool rope_vec_ok(long nrows, int dc, int dr) {
+    const int half = dr / 2;
+    return CALM_ROPE_VEC && (dc & 1) == 0 && (half & 1) == 0 && nrows < (1L << 31) - (1 << 20) && dc / 2 + half / 2 <= NT;
+}
+static int rope_vec_grid(long nrows, int dc, int dr) {
+    const int rpb = NT / (dc / 2 + dr / 4);
+    const long blocks = (nrows + rpb - 1) / rpb;
+    return (int)(blocks < 256 * 16 ? blocks : 256 * 16);
+}
 
 int calm_rope_fwd(const void* content, const void* xr, const float* inv_freq, float* table, void* out, int32_t B,
                   int32_t S, int32_t H, int32_t dc, int32_t dr, int32_t content_type, int32_t xr_type, int32_t out_type,
@@ -683,6 +792,12 @@ int calm_rope_fwd(const void* content, const void* xr, const float* inv_freq, fl
                        table, S, half);
     CALM_LAUNCH_CHECK();
     const long nrows = (long)B * S * H;
+    if (rope_vec_ok(nrows, dc, dr)) {
+        hipLaunchKernelGGL(rope_fwd_vec_kernel, dim3(rope_vec_grid(nrows, dc, dr)), dim3(NT), 0, as_stream(stream),
+                           content, xr, table, out, (int)nrows, S, H, dc, dr, content_type, xr_type, out_type);
+        CALM_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(rope_fwd_kernel, dim3(grid_for(nrows * (dc + half), NT)), dim3(NT), 0, as_stream(stream),
                        content, xr, table, out, nrows, S, H, dc, dr, content_type, xr_type, out_type);
     CALM_LAUNCH_CHECK();
@@ -699,6 +814,17 @@ int calm_rope_bwd(const void* d_out, const void* xr, const float* table, void* d
     if (!st_ok(dout_type) || !st_ok(xr_type) || !st_ok(dcontent_type) || !st_ok(dxr_type)) return CALM_E_INVAL;
     if (dr / 2 > ROPE_MAX_HALF) return CALM_E_UNSUPP;
     const long nrows = (long)B * S * H;
+    if (rope_vec_ok(nrows, dc, dr)) {
+        int gv = rope_vec_grid(nrows, dc, dr);
+        // every workgroup ends with dr/2 atomics on one cache line of d_inv_freq: few workgroups for small launches
+        // (A/B at S=80: 1024 -> 25 us, 2048 -> 36, 4096 -> 60), ~16 row passes per workgroup for large ones
+        const int want = gv / 16;
+        gv = want < CALM_ROPE_BWD_GRID ? (gv < CALM_ROPE_BWD_GRID ? gv : CALM_ROPE_BWD_GRID) : (want < 4096 ? want : 4096);
+        hipLaunchKernelGGL(rope_bwd_vec_kernel, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table, d_content,
+                           d_xr, d_inv_freq, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type, dxr_type);
+        CALM_LAUNCH_CHECK();
+        return 0;
+    }
     int g = grid_for(nrows * (dc + dr / 2), NT);
     if (g > 1024) g = 1024;
     hipLaunchKernelGGL(rope_bwd_kernel, dim3(g), dim3(NT), 0, as_stream(stream), d_out, xr, table, d_content, d_xr,

@@ -230,7 +230,8 @@ def test_layernorm(hip, emu, rows, D):
     assert rel_err(outs[1][5], outs[1][3] + skip.cuda()) < 1e-6
 
 
-@pytest.mark.parametrize("B,S,H,dc,dr", [(2, 48, 3, 0, 48), (2, 44, 3, 18, 18), (1, 224, 6, 56, 56), (3, 7, 2, 0, 6)])
+@pytest.mark.parametrize("B,S,H,dc,dr", [(2, 48, 3, 0, 48), (2, 44, 3, 18, 18), (1, 224, 6, 56, 56), (3, 7, 2, 0, 6),
+                                          (2, 40, 4, 28, 28), (3, 176, 12, 0, 44), (2, 80, 12, 10, 10), (5, 33, 12, 0, 20)])
 def test_rope(hip, emu, B, S, H, dc, dr):
     content = rnd(B, S, H * dc, seed=1) if dc else None
     xr, inv = rnd(B, S, H * dr, seed=2), torch.rand(dr // 2, generator=torch.Generator().manual_seed(3)) + 0.01
@@ -247,6 +248,30 @@ def test_rope(hip, emu, B, S, H, dc, dr):
         outs.append([out, d_x, d_f] + ([d_c] if dc else []))
     for a, b in zip(outs[1], outs[0]):
         assert rel_err(a, b) < TOL
+
+
+@pytest.mark.parametrize("B,S,H,dc,dr", [(2, 224, 12, 0, 56), (2, 176, 12, 22, 22), (2, 128, 12, 16, 16), (3, 80, 12, 0, 20)])
+@pytest.mark.parametrize("in16,out16", [(True, True), (False, True), (True, False)])
+def test_rope_bf16_tensors(hip, emu, B, S, H, dc, dr, in16, out16):
+    """bf16 pipeline: projection outputs (content, xr) and / or q, k (out) stored as bf16; gradients take the type of
+    their tensors.  Same arithmetic in fp32 on both sides, one rounding at each bf16 store: 2^-8 relative."""
+    tin, tout = (torch.bfloat16 if in16 else torch.float32), (torch.bfloat16 if out16 else torch.float32)
+    content = rnd(B, S, H * dc, seed=1).to(tin) if dc else None
+    xr, inv = rnd(B, S, H * dr, seed=2).to(tin), torch.rand(dr // 2, generator=torch.Generator().manual_seed(3)) + 0.01
+    g = rnd(B, S, H * (dc + dr), seed=4).to(tout)
+    outs = []
+    for be, dev in ((emu, "cpu"), (hip, "cuda")):
+        mv = lambda t: None if t is None else t.to(dev)
+        table = torch.empty(2 * S * (dr // 2), device=dev)
+        out = torch.empty(B, S, H * (dc + dr), device=dev, dtype=tout)
+        be.rope_fwd(mv(content), mv(xr), mv(inv), table, out, B, S, H, dc, dr)
+        d_c = torch.empty(B, S, H * dc, device=dev, dtype=tin) if dc else None
+        d_x, d_f = torch.empty(B, S, H * dr, device=dev, dtype=tin), torch.zeros(dr // 2, device=dev)
+        be.rope_bwd(mv(g), mv(xr), table, d_c, d_x, d_f, B, S, H, dc, dr)
+        outs.append([out, d_x, d_f] + ([d_c] if dc else []))
+    for a, b in zip(outs[1], outs[0]):
+        assert a.dtype == b.dtype
+        assert rel_err(a.float(), b.float()) < (2.0 ** -7 if a.dtype == torch.bfloat16 else TOL)
 
 
 @pytest.mark.parametrize("rows,cols", [(100, 48), (999, 224), (17, 80), (64, 384), (3, 1)])
