@@ -322,94 +322,111 @@ __global__ __launch_bounds__(NT) void rope_bwd_kernel(const void* __restrict__ d
     for (int j = threadIdx.x; j < half; j += NT) atomicAdd(d_inv_freq + j, facc[j]);
 }
 
-// ---- two-element form (dc and dr/2 even; every shape of the model except the dr = 22 / 10 stages of reduce blocks) ----
-// The one-element kernels above cost a 64-bit division per element and, on bf16 tensors, 2-byte accesses: at the HBM
-// roofline on fp32 tensors, 2-3x off it on bf16 ones.  Here a thread owns a fixed pair of columns (so the angle
-// gradient accumulates in registers) and walks rows: 4-byte (bf16) / 8-byte (fp32) accesses, one 32-bit division per
-// row for the position, whole rows contiguous per workgroup pass.
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2_t ldt2(const void* p, long i, int type) {
-    if (type == CALM_ST_BF16) {
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        const bf16x2_t b = *reinterpret_cast<const bf16x2_t*>(reinterpret_cast<const __bf16*>(p) + i);
-        return f32x2_t{(float)b[0], (float)b[1]};
-    }
-    return *reinterpret_cast<const f32x2_t*>(reinterpret_cast<const float*>(p) + i);
-}
-__device__ __forceinline__ void stt2(void* p, long i, f32x2_t v, int type) {
-    if (type == CALM_ST_BF16) {
-        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-        *reinterpret_cast<bf16x2_t*>(reinterpret_cast<__bf16*>(p) + i) = bf16x2_t{(__bf16)v[0], (__bf16)v[1]};
+// ---- row-walking form ----
+// The one-element-per-thread kernels above cost a 64-bit division per element, an LDS atomic per rotated pair and, on
+// bf16 tensors, 2-byte accesses: near the HBM roofline on fp32 tensors at round 1's sizes, 2-3x off it on bf16 ones.
+// Here a thread owns a fixed rotation pair (VW = 2 adjacent pairs when dc and dr/2 are even: 4-byte bf16 / 8-byte fp32
+// accesses) — so the angle gradient accumulates in registers — plus the content columns congruent to it, and walks
+// rows: one 32-bit division per row for the position, no divergence between the copy and the rotation, whole rows
+// contiguous per workgroup pass.
+template <int VW> struct RopeVec { typedef float type __attribute__((ext_vector_type(VW))); };
+template <> struct RopeVec<1> { typedef float type; };
+template <int VW>
+__device__ __forceinline__ typename RopeVec<VW>::type ldtv(const void* p, long i, int type) {
+    if constexpr (VW == 1) {
+        return ldt(p, i, type);
     } else {
-        *reinterpret_cast<f32x2_t*>(reinterpret_cast<float*>(p) + i) = v;
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        if (type == CALM_ST_BF16) {
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const bf16x2_t b = *reinterpret_cast<const bf16x2_t*>(reinterpret_cast<const __bf16*>(p) + i);
+            return f32x2_t{(float)b[0], (float)b[1]};
+        }
+        return *reinterpret_cast<const f32x2_t*>(reinterpret_cast<const float*>(p) + i);
     }
+}
+template <int VW>
+__device__ __forceinline__ void sttv(void* p, long i, typename RopeVec<VW>::type v, int type) {
+    if constexpr (VW == 1) {
+        stt(p, i, v, type);
+    } else {
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        if (type == CALM_ST_BF16) {
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<bf16x2_t*>(reinterpret_cast<__bf16*>(p) + i) = bf16x2_t{(__bf16)v[0], (__bf16)v[1]};
+        } else {
+            *reinterpret_cast<f32x2_t*>(reinterpret_cast<float*>(p) + i) = v;
+        }
+    }
+}
+template <int VW>
+__device__ __forceinline__ typename RopeVec<VW>::type ldf(const float* p) {
+    return *reinterpret_cast<const typename RopeVec<VW>::type*>(p);
 }
 
+template <int VW>
 __global__ __launch_bounds__(NT) void rope_fwd_vec_kernel(const void* __restrict__ content, const void* __restrict__ xr,
                                                           const float* __restrict__ table, void* __restrict__ out,
                                                           int nrows, int S, int H, int dc, int dr, int content_type,
                                                           int xr_type, int out_type) {
-    const int half = dr >> 1, ic = dc >> 1, ipr = ic + (half >> 1);     // items (column pairs) per row
-    const int rpb = NT / ipr;                                            // rows per workgroup pass
-    const int r_in = threadIdx.x / ipr, j = threadIdx.x - r_in * ipr;
+    typedef typename RopeVec<VW>::type vec;
+    const int half = dr >> 1, ir = half / VW, ic = dc / VW;             // rotation / content items per row
+    const int rpb = NT / ir;                                            // rows per workgroup pass
+    const int r_in = threadIdx.x / ir, j = threadIdx.x - r_in * ir;
     if (r_in >= rpb) return;
-    const float* cosT = table;
-    const float* sinT = table + (long)S * half;
-#pragma unroll 2
+    const int jj = VW * j;
+    const float* cosT = table + jj;
+    const float* sinT = table + (long)S * half + jj;
     for (int row = blockIdx.x * rpb + r_in; row < nrows; row += gridDim.x * rpb) {
         const long o = (long)row * (dc + dr);
-        if (j < ic) {
-            stt2(out, o + 2 * j, ldt2(content, (long)row * dc + 2 * j, content_type), out_type);
-        } else {
-            const int jj = 2 * (j - ic);
-            const int s = (row / H) % S;
-            const f32x2_t c = *reinterpret_cast<const f32x2_t*>(cosT + s * half + jj);
-            const f32x2_t sn = *reinterpret_cast<const f32x2_t*>(sinT + s * half + jj);
-            const f32x2_t x1 = ldt2(xr, (long)row * dr + jj, xr_type), x2 = ldt2(xr, (long)row * dr + jj + half, xr_type);
-            stt2(out, o + dc + jj, x1 * c - x2 * sn, out_type);
-            stt2(out, o + dc + jj + half, x2 * c + x1 * sn, out_type);
-        }
+        const int s = (row / H) % S;
+        const vec c = ldf<VW>(cosT + s * half), sn = ldf<VW>(sinT + s * half);
+        const vec x1 = ldtv<VW>(xr, (long)row * dr + jj, xr_type), x2 = ldtv<VW>(xr, (long)row * dr + jj + half, xr_type);
+        for (int k = j; k < ic; k += ir)
+            sttv<VW>(out, o + VW * k, ldtv<VW>(content, (long)row * dc + VW * k, content_type), out_type);
+        sttv<VW>(out, o + dc + jj, x1 * c - x2 * sn, out_type);
+        sttv<VW>(out, o + dc + jj + half, x2 * c + x1 * sn, out_type);
     }
 }
 
+template <int VW>
 __global__ __launch_bounds__(NT) void rope_bwd_vec_kernel(const void* __restrict__ d_out, const void* __restrict__ xr,
                                                           const float* __restrict__ table, void* __restrict__ d_content,
                                                           void* __restrict__ d_xr, float* __restrict__ d_inv_freq,
                                                           int nrows, int S, int H, int dc, int dr, int dout_type,
                                                           int xr_type, int dcontent_type, int dxr_type) {
+    typedef typename RopeVec<VW>::type vec;
     __shared__ float facc[ROPE_MAX_HALF];
-    const int half = dr >> 1, ic = dc >> 1, ipr = ic + (half >> 1);
+    const int half = dr >> 1, ir = half / VW, ic = dc / VW;
     for (int k = threadIdx.x; k < half; k += NT) facc[k] = 0.f;
     __syncthreads();
-    const int rpb = NT / ipr;
-    const int r_in = threadIdx.x / ipr, j = threadIdx.x - r_in * ipr;
-    const float* cosT = table;
-    const float* sinT = table + (long)S * half;
-    const bool rot = r_in < rpb && j >= ic;
-    const int jj = 2 * (j - ic);
-    f32x2_t acc = {0.f, 0.f};
+    const int rpb = NT / ir;
+    const int r_in = threadIdx.x / ir, j = threadIdx.x - r_in * ir;
+    const int jj = VW * j;
+    const float* cosT = table + jj;
+    const float* sinT = table + (long)S * half + jj;
+    vec acc = vec(0.f);
     if (r_in < rpb) {
-#pragma unroll 2
         for (int row = blockIdx.x * rpb + r_in; row < nrows; row += gridDim.x * rpb) {
             const long go = (long)row * (dc + dr);
-            if (j < ic) {
-                stt2(d_content, (long)row * dc + 2 * j, ldt2(d_out, go + 2 * j, dout_type), dcontent_type);
-            } else {
-                const int s = (row / H) % S;
-                const f32x2_t c = *reinterpret_cast<const f32x2_t*>(cosT + s * half + jj);
-                const f32x2_t sn = *reinterpret_cast<const f32x2_t*>(sinT + s * half + jj);
-                const f32x2_t g1 = ldt2(d_out, go + dc + jj, dout_type), g2 = ldt2(d_out, go + dc + jj + half, dout_type);
-                const f32x2_t x1 = ldt2(xr, (long)row * dr + jj, xr_type), x2 = ldt2(xr, (long)row * dr + jj + half, xr_type);
-                stt2(d_xr, (long)row * dr + jj, g1 * c + g2 * sn, dxr_type);
-                stt2(d_xr, (long)row * dr + jj + half, g2 * c - g1 * sn, dxr_type);
-                const f32x2_t dang = g1 * (-x1 * sn - x2 * c) + g2 * (-x2 * sn + x1 * c);
-                acc += dang * (float)s;
-            }
+            const int s = (row / H) % S;
+            const vec c = ldf<VW>(cosT + s * half), sn = ldf<VW>(sinT + s * half);
+            const vec g1 = ldtv<VW>(d_out, go + dc + jj, dout_type), g2 = ldtv<VW>(d_out, go + dc + jj + half, dout_type);
+            const vec x1 = ldtv<VW>(xr, (long)row * dr + jj, xr_type), x2 = ldtv<VW>(xr, (long)row * dr + jj + half, xr_type);
+            for (int k = j; k < ic; k += ir)
+                sttv<VW>(d_content, (long)row * dc + VW * k, ldtv<VW>(d_out, go + VW * k, dout_type), dcontent_type);
+            sttv<VW>(d_xr, (long)row * dr + jj, g1 * c + g2 * sn, dxr_type);
+            sttv<VW>(d_xr, (long)row * dr + jj + half, g2 * c - g1 * sn, dxr_type);
+            // d/d(angle): y1 = x1 c - x2 s, y2 = x2 c + x1 s ; angle = s * inv_freq[jj]
+            const vec dang = g1 * (-x1 * sn - x2 * c) + g2 * (-x2 * sn + x1 * c);
+            acc += dang * (float)s;
         }
-    }
-    if (rot) {
-        atomicAdd(&facc[jj], acc[0]);
-        atomicAdd(&facc[jj + 1], acc[1]);
+        if constexpr (VW == 1) {
+            atomicAdd(&facc[jj], acc);
+        } else {
+            atomicAdd(&facc[jj], acc[0]);
+            atomicAdd(&facc[jj + 1], acc[1]);
+        }
     }
     __syncthreads();
     for (int k = threadIdx.x; k < half; k += NT) atomicAdd(d_inv_freq + k, facc[k]);
@@ -769,13 +786,13 @@ int calm_layernorm_bwd(const void* dy, const float* x, const float* w, const flo
 }
 
 static bool st_ok(int t) { return t == CALM_ST_F32 || t == CALM_ST_BF16; }
-// two-element RoPE kernels: column pairs must not straddle the content / first-half / second-half boundaries
-static bool rope_vec_ok(long nrows, int dc, int dr) {
-    const int half = dr / 2;
-    return CALM_ROPE_VEC && (dc & 1) == 0 && (half & 1) == 0 && nrows < (1L << 31) - (1 << 20) && dc / 2 + half / 2 <= NT;
+// row-walking RoPE kernels: 32-bit row index; VW = 2 when column pairs do not straddle the content / half boundaries
+static bool rope_vec_ok(long nrows, int dr) {
+    return CALM_ROPE_VEC && nrows < (1L << 31) - (1 << 22) && dr / 2 <= NT && dr / 2 <= ROPE_MAX_HALF;
 }
+static int rope_vw(int dc, int dr) { return ((dc & 1) == 0 && ((dr / 2) & 1) == 0) ? 2 : 1; }
 static int rope_vec_grid(long nrows, int dc, int dr) {
-    const int rpb = NT / (dc / 2 + dr / 4);
+    const int rpb = NT / (dr / 2 / rope_vw(dc, dr));
     const long blocks = (nrows + rpb - 1) / rpb;
     return (int)(blocks < 256 * 16 ? blocks : 256 * 16);
 }
@@ -792,9 +809,14 @@ int calm_rope_fwd(const void* content, const void* xr, const float* inv_freq, fl
                        table, S, half);
     CALM_LAUNCH_CHECK();
     const long nrows = (long)B * S * H;
-    if (rope_vec_ok(nrows, dc, dr)) {
-        hipLaunchKernelGGL(rope_fwd_vec_kernel, dim3(rope_vec_grid(nrows, dc, dr)), dim3(NT), 0, as_stream(stream),
-                           content, xr, table, out, (int)nrows, S, H, dc, dr, content_type, xr_type, out_type);
+    if (rope_vec_ok(nrows, dr)) {
+        const dim3 gv(rope_vec_grid(nrows, dc, dr));
+        if (rope_vw(dc, dr) == 2)
+            hipLaunchKernelGGL(rope_fwd_vec_kernel<2>, gv, dim3(NT), 0, as_stream(stream), content, xr, table, out,
+                               (int)nrows, S, H, dc, dr, content_type, xr_type, out_type);
+        else
+            hipLaunchKernelGGL(rope_fwd_vec_kernel<1>, gv, dim3(NT), 0, as_stream(stream), content, xr, table, out,
+                               (int)nrows, S, H, dc, dr, content_type, xr_type, out_type);
         CALM_LAUNCH_CHECK();
         return 0;
     }
@@ -814,14 +836,20 @@ int calm_rope_bwd(const void* d_out, const void* xr, const float* table, void* d
     if (!st_ok(dout_type) || !st_ok(xr_type) || !st_ok(dcontent_type) || !st_ok(dxr_type)) return CALM_E_INVAL;
     if (dr / 2 > ROPE_MAX_HALF) return CALM_E_UNSUPP;
     const long nrows = (long)B * S * H;
-    if (rope_vec_ok(nrows, dc, dr)) {
+    if (rope_vec_ok(nrows, dr)) {
         int gv = rope_vec_grid(nrows, dc, dr);
         // every workgroup ends with dr/2 atomics on one cache line of d_inv_freq: few workgroups for small launches
         // (A/B at S=80: 1024 -> 25 us, 2048 -> 36, 4096 -> 60), ~16 row passes per workgroup for large ones
         const int want = gv / 16;
         gv = want < CALM_ROPE_BWD_GRID ? (gv < CALM_ROPE_BWD_GRID ? gv : CALM_ROPE_BWD_GRID) : (want < 4096 ? want : 4096);
-        hipLaunchKernelGGL(rope_bwd_vec_kernel, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table, d_content,
-                           d_xr, d_inv_freq, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type, dxr_type);
+        if (rope_vw(dc, dr) == 2)
+            hipLaunchKernelGGL(rope_bwd_vec_kernel<2>, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table,
+                               d_content, d_xr, d_inv_freq, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type,
+                               dxr_type);
+        else
+            hipLaunchKernelGGL(rope_bwd_vec_kernel<1>, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table,
+                               d_content, d_xr, d_inv_freq, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type,
+                               dxr_type);
         CALM_LAUNCH_CHECK();
         return 0;
     }

@@ -16,7 +16,7 @@ def t_med(fn, n=12, warm=3):
     return t[len(t) // 2]
 print(os.environ.get("CALM_VIT_LIB", "default lib"))
 for dt in (torch.float32, torch.bfloat16):
-    for B, S, H, dc, dr in ((256, 224, 12, 0, 56), (256, 224, 12, 28, 28), (256, 176, 12, 0, 44), (256, 128, 12, 0, 32), (256, 80, 12, 0, 20)):
+    for B, S, H, dc, dr in ((256, 224, 12, 0, 56), (256, 224, 12, 28, 28), (256, 176, 12, 0, 44), (256, 176, 12, 22, 22), (256, 128, 12, 0, 32), (256, 80, 12, 0, 20), (256, 80, 12, 10, 10)):
         esz = 4 if dt == torch.float32 else 2
         content = torch.randn(B, S, H * dc, device="cuda").to(dt) if dc else None
         xr = torch.randn(B, S, H * dr, device="cuda").to(dt)
