@@ -180,7 +180,10 @@ def pmc_rows(kernel_prefix):
     import hashlib
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_summary.csv")))       # names sort by round
     for f in reversed(files):                              # newest summary that has this kernel family
-        rows = [r for r in csv.DictReader(open(f)) if r["kernel"].startswith(kernel_prefix)]
+        # (rocprofv3 leaves names with __bf16 template arguments mangled: _ZN16calm_gemm_detail17gemm_bf16w_kernelIDF16b...)
+        parts = kernel_prefix.split("::")
+        rows = [r for r in csv.DictReader(open(f)) if r["kernel"].startswith(kernel_prefix) or
+                (r["kernel"].startswith("_ZN") and all(x in r["kernel"] for x in parts))]
         if not rows:
             continue
         stale = True                                       # a summary without a stamp cannot be vouched for

@@ -65,6 +65,8 @@ class _ZeroArena:
     def __init__(self, chunk_floats=1 << 18):
         self.CHUNK = chunk_floats
         self.buf, self.off, self.lock = None, 0, threading.Lock()
+        self.owner = None            # (device, stream) the current chunk was allocated on: the caching allocator ties a
+                                     # block to its allocation stream, so slices are only handed out on that stream
 
     def take(self, shape, like):
         n = int(math.prod(shape))
@@ -72,10 +74,11 @@ class _ZeroArena:
         capturing = like.is_cuda and torch.cuda.is_current_stream_capturing()
         if not ZERO_ARENA or m > self.CHUNK // 4 or like.dtype != torch.float32 or capturing:
             return torch.zeros(shape, dtype=like.dtype, device=like.device)
+        owner = (like.device, torch.cuda.current_stream(like.device).cuda_stream if like.is_cuda else 0)
         with self.lock:
-            if self.buf is None or self.buf.device != like.device or self.off + m > self.CHUNK:
+            if self.buf is None or self.owner != owner or self.off + m > self.CHUNK:
                 self.buf = torch.zeros(self.CHUNK, dtype=torch.float32, device=like.device)
-                self.off = 0
+                self.off, self.owner = 0, owner
             v = self.buf[self.off:self.off + n].view(shape)
             self.off += m
         return v
