@@ -172,15 +172,19 @@ __global__ __launch_bounds__(NTHREADS, NPASS == 3 ? 2 : CALM_GEMM_BF16_WAVES) vo
 
     typedef TCursor<TA, AKC, BM, BM, NTHREADS, MC_LD> CurA;
     typedef TCursor<TB, BKC, BM, BN_, NTHREADS, MC_LD> CurB;
-    typename CurA::vec_t ra[CurA::NV];
-    typename CurB::vec_t rb[CurB::NV];
+    // bf16 tensors: two k-tiles of global loads in flight (see gemm_bf16w_kernel) — what the short reductions of the
+    // per-image and K <= 256 products are made of is exposed load latency, one per k-tile at distance 1
+    constexpr int NSET = (sizeof(TA) == 2 && sizeof(TB) == 2 && NPASS == 1 && CALM_GEMM_BF16_DEEP) ? 2 : 1;
+    typename CurA::vec_t ra[NSET][CurA::NV];
+    typename CurB::vec_t rb[NSET][CurB::NV];
     CurA ca;
     CurB cb;
     // one copy of the k-loop per case (whole k-tiles / tailed K): see OperandCursor::load
     auto k_loop = [&](auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     int cur_b = -1;
-    auto fetch = [&](int kb) {
+    auto fetch = [&](int kb, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
         const int b = p.kb_total == p.kpb ? 0 : kb / p.kpb;
         const int k0 = (kb - b * p.kpb) * CK;
         if (b != cur_b) {
@@ -189,25 +193,30 @@ __global__ __launch_bounds__(NTHREADS, NPASS == 3 ? 2 : CALM_GEMM_BF16_WAVES) vo
             cb.init(operand_base<TB>(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, k0);
             cur_b = b;
         }
-        ca.template load<FULL>(p.K - k0, ra);
-        cb.template load<FULL>(p.K - k0, rb);
+        ca.template load<FULL>(p.K - k0, ra[SET]);
+        cb.template load<FULL>(p.K - k0, rb[SET]);
     };
-    auto stash = [&](int st) {
-        ca.template store<NPASS>(lds[st][0][0], lds[st][0][NPL - 1], ra);
-        cb.template store<NPASS>(lds[st][1][0], lds[st][1][NPL - 1], rb);
+    auto stash = [&](int st, auto set_tag) {
+        constexpr int SET = decltype(set_tag)::value;
+        ca.template store<NPASS>(lds[st][0][0], lds[st][0][NPL - 1], ra[SET]);
+        cb.template store<NPASS>(lds[st][1][0], lds[st][1][NPL - 1], rb[SET]);
     };
+    typedef std::integral_constant<int, 0> S0;
+    typedef std::integral_constant<int, NSET - 1> S1;
 
     int buf = 0;
     if (kb_begin < kb_end) {
-        fetch(kb_begin);
-        stash(0);
+        fetch(kb_begin, S0{});
+        stash(0, S0{});
     }
+    if constexpr (NSET == 2)
+        if (kb_begin + 1 < kb_end) fetch(kb_begin + 1, S1{});
     __syncthreads();
 
-    for (int kb = kb_begin; kb < kb_end; ++kb) {
-        const bool more = kb + 1 < kb_end;
+    auto iteration = [&](int kb, auto near_tag, auto far_tag, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;      // both the far fetch and the near stash exist
         if (p.reduce_group && kb != kb_begin && kb % p.kpb == 0) group_rescale<MT, NT>(p, acc, kb / p.kpb);
-        if (more) fetch(kb + 1);
+        if (STEADY || kb + NSET < kb_end) fetch(kb + NSET, far_tag);
 #pragma unroll
         for (int s = 0; s < CK / 16; ++s) {
             bf16x8 ah[MT], bh[NT], al[MT], bl[NT];
@@ -232,9 +241,25 @@ __global__ __launch_bounds__(NTHREADS, NPASS == 3 ? 2 : CALM_GEMM_BF16_WAVES) vo
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                 }
         }
-        if (more) stash(buf ^ 1);
+        if (STEADY || kb + 1 < kb_end) stash(buf ^ 1, near_tag);
         __syncthreads();
         buf ^= 1;
+    };
+    if constexpr (NSET == 2) {
+        // steady state peeled from the tail: with a CONDITIONAL far fetch the compiler must assume the path on which
+        // it was skipped, where the near set's loads are the newest, and waits with vmcnt(0) before the stash — which
+        // also waits for the far loads just issued and serialises the two tiles again
+        int kb = kb_begin;
+        for (; kb + 3 < kb_end; kb += 2) {
+            iteration(kb, S1{}, S0{}, std::true_type{});
+            iteration(kb + 1, S0{}, S1{}, std::true_type{});
+        }
+        for (; kb < kb_end; kb += 2) {
+            iteration(kb, S1{}, S0{}, std::false_type{});
+            if (kb + 1 < kb_end) iteration(kb + 1, S0{}, S1{}, std::false_type{});
+        }
+    } else {
+        for (int kb = kb_begin; kb < kb_end; ++kb) iteration(kb, S0{}, S0{}, std::false_type{});
     }
     };
     if (p.K % CK == 0) k_loop(std::true_type{});
@@ -290,7 +315,8 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
     // The kernel is bound by the latency of its global loads (bytes in flight per CU), not by the matrix pipe: bf16
     // tensors need only 12 staging registers per k-tile, so TWO k-tiles are kept in flight (register sets 0/1,
     // prefetch distance 2); fp32 tensors (24 registers per k-tile) keep distance 1 to stay within 128 VGPRs.
-    constexpr int NSET = (sizeof(TA) == 2 && sizeof(TB) == 2 && CALM_GEMM_BF16_DEEP) ? 2 : 1;
+    // (a row-contiguous A operand needs more address registers: with two sets the 128-VGPR budget spills into the k-loop)
+    constexpr int NSET = (sizeof(TA) == 2 && sizeof(TB) == 2 && AKC && CALM_GEMM_BF16_DEEP) ? 2 : 1;
     CurA ca;
     CurB cb;
     typename CurA::vec_t ra[NSET][CurA::NV];
@@ -330,9 +356,10 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
 
     // one k-tile: issue the loads of tile kb+NSET into register set FAR, multiply tile kb out of LDS stage `buf`,
     // move tile kb+1 (register set NEAR: loaded a whole iteration ago when NSET == 2) into the other stage
-    auto iteration = [&](int kb, auto near_tag, auto far_tag) {
+    auto iteration = [&](int kb, auto near_tag, auto far_tag, auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;      // both the far fetch and the near stash exist
         if (p.reduce_group && kb != kb_begin && kb % p.kpb == 0) group_rescale<MT, NT>(p, acc, kb / p.kpb);
-        if (kb + NSET < kb_end) fetch(kb + NSET, far_tag);
+        if (STEADY || kb + NSET < kb_end) fetch(kb + NSET, far_tag);
 #pragma unroll
         for (int s = 0; s < CK / 16; ++s) {
             bf16x8 af[MT], bf[NT];
@@ -346,17 +373,25 @@ __global__ __launch_bounds__(WTHREADS, 4) void gemm_bf16w_kernel(const GemmP p) 
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (kb + 1 < kb_end) stash(buf ^ 1, near_tag);
+        if (STEADY || kb + 1 < kb_end) stash(buf ^ 1, near_tag);
         __syncthreads();
         buf ^= 1;
     };
     if constexpr (NSET == 2) {
-        for (int kb = kb_begin; kb < kb_end; kb += 2) {
-            iteration(kb, S1{}, S0{});
-            if (kb + 1 < kb_end) iteration(kb + 1, S0{}, S1{});
+        // steady state peeled from the tail: with a CONDITIONAL far fetch the compiler must assume the path on which
+        // it was skipped, where the near set's loads are the newest, and waits with vmcnt(0) before the stash — which
+        // also waits for the far loads just issued and serialises the two tiles again
+        int kb = kb_begin;
+        for (; kb + 3 < kb_end; kb += 2) {
+            iteration(kb, S1{}, S0{}, std::true_type{});
+            iteration(kb + 1, S0{}, S1{}, std::true_type{});
+        }
+        for (; kb < kb_end; kb += 2) {
+            iteration(kb, S1{}, S0{}, std::false_type{});
+            if (kb + 1 < kb_end) iteration(kb + 1, S0{}, S1{}, std::false_type{});
         }
     } else {
-        for (int kb = kb_begin; kb < kb_end; ++kb) iteration(kb, S0{}, S0{});
+        for (int kb = kb_begin; kb < kb_end; ++kb) iteration(kb, S0{}, S0{}, std::false_type{});
     }
     };
     if (p.K % CK == 0) k_loop(std::true_type{});
