@@ -89,6 +89,26 @@ def test_gemm_layouts_and_epilogues(hip, emu, M, N, K, batch, akc, bkc, epi):
         assert rel_err(kw_hip["C_pre"], kw["C_pre"]) < TOL
 
 
+def test_gemm_epilogue_tensors_off_16_byte_alignment(hip, emu):
+    """The vector epilogue needs every epilogue tensor addressable in aligned groups of 4 columns; a C / bias /
+    residual that starts 4 bytes into an allocation (a slice) must fall back to the one-element form, same results."""
+    M, N, K = 200, 136, 72
+    A, B = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    bias_buf, res_buf, c_buf = rnd(N + 1, seed=3), rnd(M * N + 1, seed=4), rnd(M * N + 1, seed=5)
+    for off_c, off_b, off_r in ((1, 0, 0), (0, 1, 0), (0, 0, 1), (0, 0, 0)):
+        bias = bias_buf[off_b:off_b + N]
+        res = res_buf[off_r:off_r + M * N].view(M, N)
+        C_ref = c_buf[off_c:off_c + M * N].view(M, N).clone()
+        cg = c_buf.clone().cuda()
+        C_hip = cg[off_c:off_c + M * N].view(M, N)
+        kw = dict(alpha=0.5, bias=bias, residual=res, r=(N, 0, 0), act=1)
+        emu.gemm(A, B, C_ref, M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), **kw)
+        bg, rg = bias_buf.cuda(), res_buf.cuda()
+        hip.gemm(A.cuda(), B.cuda(), C_hip, M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), alpha=0.5,
+                 bias=bg[off_b:off_b + N], residual=rg[off_r:off_r + M * N].view(M, N), r=(N, 0, 0), act=1)
+        assert rel_err(C_hip, C_ref) < TOL, (off_c, off_b, off_r)
+
+
 def test_gemm_head_strided_batches(hip, emu):
     """The attention GEMMs address heads through strides inside [B,S,H*hd] tensors."""
     B_, H, S, hd = 2, 3, 48, 20
