@@ -62,18 +62,34 @@ __global__ __launch_bounds__(FW_NT) void cnn_fwd_kernel(const float* __restrict_
     if (tid < 3 * CH) w4s[tid] = W.w4[tid] * i4;
     if (tid < 3) w4s[3 * CH + tid] = W.b4[tid];
 
-    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // the input region of the NEXT tile is requested right after this tile's has been handed to LDS, so its global
+    // latency runs under the GELU work instead of in front of it (stall counters: 45 % of the wave cycles waited)
+    constexpr int FPRE = (FH * FH * 3 + FW_NT - 1) / FW_NT;
+    float pre[FPRE];
+    auto request = [&](long tile) {
         const int b = (int)(tile / (tiles_per_side * tiles_per_side));
         const int tt = (int)(tile - (long)b * tiles_per_side * tiles_per_side);
         const int y0 = (tt / tiles_per_side) * T, x0 = (tt % tiles_per_side) * T;
         const float* xb = x + (long)b * S * S * 3;
-        __syncthreads();                                   // previous tile's LDS fully consumed
-        for (int e = tid; e < FH * FH * 3; e += FW_NT) {
+#pragma unroll
+        for (int k = 0; k < FPRE; ++k) {
+            const int e = tid + k * FW_NT;
             const int p = e / 3, ch = e - 3 * p;
             const int yy = y0 - 1 + p / FH, xx = x0 - 1 + p % FH;
-            xs[e] = (yy >= 0 && yy < S && xx >= 0 && xx < S) ? xb[((long)yy * S + xx) * 3 + ch] : 0.f;
+            pre[k] = (e < FH * FH * 3 && yy >= 0 && yy < S && xx >= 0 && xx < S) ? xb[((long)yy * S + xx) * 3 + ch] : 0.f;
         }
+    };
+    if (blockIdx.x < n_tiles) request(blockIdx.x);
+    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = (int)(tile / (tiles_per_side * tiles_per_side));
+        const int tt = (int)(tile - (long)b * tiles_per_side * tiles_per_side);
+        const int y0 = (tt / tiles_per_side) * T, x0 = (tt % tiles_per_side) * T;
+        __syncthreads();                                   // previous tile's LDS fully consumed
+#pragma unroll
+        for (int k = 0; k < FPRE; ++k)
+            if (tid + k * FW_NT < FH * FH * 3) xs[tid + k * FW_NT] = pre[k];
         __syncthreads();
+        if (tile + gridDim.x < n_tiles) request(tile + gridDim.x);
         // (out-of-image pixels: computed unconditionally on the zero-padded x and multiplied by 0 — a select makes the
         // compiler wrap the GELU in an exec-mask branch, which keeps two unrolled iterations from interleaving)
 #pragma unroll 2
@@ -159,24 +175,44 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
 #pragma unroll
     for (int k = 0; k < 9; ++k) a_g2[k] = zero2;
 
-    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    // next tile's x / dy regions requested right after this tile's have been handed to LDS (see the forward kernel)
+    constexpr int XPRE = (H2 * H2 * 3 + BW_NT - 1) / BW_NT, DPRE = (H1 * H1 * 3 + BW_NT - 1) / BW_NT;
+    float prex[XPRE], pred[DPRE];
+    auto request = [&](long tile) {
         const int b = (int)(tile / (tiles_per_side * tiles_per_side));
         const int tt = (int)(tile - (long)b * tiles_per_side * tiles_per_side);
         const int y0 = (tt / tiles_per_side) * T, x0 = (tt % tiles_per_side) * T;
         const float* xb = x + (long)b * S * S * 3;
         const float* gb = dy + (long)b * S * S * 3;
-        __syncthreads();
-        for (int e = tid; e < H2 * H2 * 3; e += BW_NT) {
+#pragma unroll
+        for (int k = 0; k < XPRE; ++k) {
+            const int e = tid + k * BW_NT;
             const int p = e / 3, ch = e - 3 * p;
             const int yy = y0 - 2 + p / H2, xx = x0 - 2 + p % H2;
-            xs[e] = (yy >= 0 && yy < S && xx >= 0 && xx < S) ? xb[((long)yy * S + xx) * 3 + ch] : 0.f;
+            prex[k] = (e < H2 * H2 * 3 && yy >= 0 && yy < S && xx >= 0 && xx < S) ? xb[((long)yy * S + xx) * 3 + ch] : 0.f;
         }
-        for (int e = tid; e < H1 * H1 * 3; e += BW_NT) {
+#pragma unroll
+        for (int k = 0; k < DPRE; ++k) {
+            const int e = tid + k * BW_NT;
             const int p = e / 3, ch = e - 3 * p;
             const int yy = y0 - 1 + p / H1, xx = x0 - 1 + p % H1;
-            dys[e] = (yy >= 0 && yy < S && xx >= 0 && xx < S) ? gb[((long)yy * S + xx) * 3 + ch] : 0.f;
+            pred[k] = (e < H1 * H1 * 3 && yy >= 0 && yy < S && xx >= 0 && xx < S) ? gb[((long)yy * S + xx) * 3 + ch] : 0.f;
         }
+    };
+    if (blockIdx.x < n_tiles) request(blockIdx.x);
+    for (long tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int b = (int)(tile / (tiles_per_side * tiles_per_side));
+        const int tt = (int)(tile - (long)b * tiles_per_side * tiles_per_side);
+        const int y0 = (tt / tiles_per_side) * T, x0 = (tt % tiles_per_side) * T;
         __syncthreads();
+#pragma unroll
+        for (int k = 0; k < XPRE; ++k)
+            if (tid + k * BW_NT < H2 * H2 * 3) xs[tid + k * BW_NT] = prex[k];
+#pragma unroll
+        for (int k = 0; k < DPRE; ++k)
+            if (tid + k * BW_NT < H1 * H1 * 3) dys[tid + k * BW_NT] = pred[k];
+        __syncthreads();
+        if (tile + gridDim.x < n_tiles) request(tile + gridDim.x);
         // h1 on the 20x20 region
 #pragma unroll 2
         for (int p = g; p < H2 * H2; p += BG) {

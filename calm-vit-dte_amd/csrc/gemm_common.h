@@ -25,6 +25,9 @@ constexpr int WTHREADS = 512, WBM = 256, WBN = 128;     // its wide tile
 #ifndef CALM_GEMM_VEC_EPILOGUE
 #define CALM_GEMM_VEC_EPILOGUE 1     // 0: always the one-element-per-access epilogue (A/B runs)
 #endif
+#ifndef CALM_GEMM_KC_SWIZZLE
+#define CALM_GEMM_KC_SWIZZLE 1     // bf16 k-contiguous staging: transposed row slots per wave (conflict-free ds_write_b128); 0 for A/B
+#endif
 #ifndef CALM_GEMM_BF16_DEEP
 #define CALM_GEMM_BF16_DEEP 1       // bf16-tensor kernels keep two k-tiles of global loads in flight (0: one, for A/B runs)
 #endif
