@@ -182,8 +182,16 @@ __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const void* __restrict__
             }
         };
         const float mu = mean[row], rs = rstd[row];
-        f32x4 xh[NV], gv[NV];
+        f32x4 xh[NV], gv[NV], av[NV];
         float c1 = 0.f, c2 = 0.f;
+        // the skip-connection gradient is requested together with x and dy: one memory latency per row, not a second
+        // one behind the two wave reductions
+        const f32x4* ar = dx_add ? reinterpret_cast<const f32x4*>(dx_add + row * D) : nullptr;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c4 = lane + 64 * i;
+            av[i] = (ar && c4 < nv4) ? ar[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c4 = lane + 64 * i;
@@ -199,12 +207,11 @@ __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const void* __restrict__
         }
         c1 = wave_sum(c1) / D; c2 = wave_sum(c2) / D;
         f32x4* dr = reinterpret_cast<f32x4*>(dx + row * D);
-        const f32x4* ar = dx_add ? reinterpret_cast<const f32x4*>(dx_add + row * D) : nullptr;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c4 = lane + 64 * i;
             if (c4 < nv4) {
-                f32x4 o = ar ? ar[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};      // gradient of the skip connection around LN
+                f32x4 o = av[i];                                           // gradient of the skip connection around LN
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     o[e] += rs * (gv[i][e] * wv[i][e] - c1 - xh[i][e] * c2);
