@@ -289,6 +289,9 @@ constexpr int ROPE_MAX_HALF = 256;
 #ifndef CALM_ROPE_VEC
 #define CALM_ROPE_VEC 1        // 0: always the one-element kernels (A/B runs)
 #endif
+#ifndef CALM_ROPE_VW4
+#define CALM_ROPE_VW4 1
+#endif
 #ifndef CALM_ROPE_BWD_GRID
 #define CALM_ROPE_BWD_GRID 1024
 #endif
@@ -343,13 +346,16 @@ __device__ __forceinline__ typename RopeVec<VW>::type ldtv(const void* p, long i
     if constexpr (VW == 1) {
         return ldt(p, i, type);
     } else {
-        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        typedef typename RopeVec<VW>::type fvec;
         if (type == CALM_ST_BF16) {
-            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-            const bf16x2_t b = *reinterpret_cast<const bf16x2_t*>(reinterpret_cast<const __bf16*>(p) + i);
-            return f32x2_t{(float)b[0], (float)b[1]};
+            typedef __bf16 bvec __attribute__((ext_vector_type(VW)));
+            const bvec b = *reinterpret_cast<const bvec*>(reinterpret_cast<const __bf16*>(p) + i);
+            fvec r;
+#pragma unroll
+            for (int e = 0; e < VW; ++e) r[e] = (float)b[e];
+            return r;
         }
-        return *reinterpret_cast<const f32x2_t*>(reinterpret_cast<const float*>(p) + i);
+        return *reinterpret_cast<const fvec*>(reinterpret_cast<const float*>(p) + i);
     }
 }
 template <int VW>
@@ -357,12 +363,15 @@ __device__ __forceinline__ void sttv(void* p, long i, typename RopeVec<VW>::type
     if constexpr (VW == 1) {
         stt(p, i, v, type);
     } else {
-        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        typedef typename RopeVec<VW>::type fvec;
         if (type == CALM_ST_BF16) {
-            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<bf16x2_t*>(reinterpret_cast<__bf16*>(p) + i) = bf16x2_t{(__bf16)v[0], (__bf16)v[1]};
+            typedef __bf16 bvec __attribute__((ext_vector_type(VW)));
+            bvec b;
+#pragma unroll
+            for (int e = 0; e < VW; ++e) b[e] = (__bf16)v[e];
+            *reinterpret_cast<bvec*>(reinterpret_cast<__bf16*>(p) + i) = b;
         } else {
-            *reinterpret_cast<f32x2_t*>(reinterpret_cast<float*>(p) + i) = v;
+            *reinterpret_cast<fvec*>(reinterpret_cast<float*>(p) + i) = v;
         }
     }
 }
@@ -370,6 +379,26 @@ template <int VW>
 __device__ __forceinline__ typename RopeVec<VW>::type ldf(const float* p) {
     return *reinterpret_cast<const typename RopeVec<VW>::type*>(p);
 }
+
+// (h, s) of row = (b S + s) H + h under row += stride, without divisions in the loop
+struct RopePos {
+    int h, s, dh, ds, H, S;
+    __device__ __forceinline__ RopePos(int row0, int stride, int H_, int S_) : H(H_), S(S_) {
+        const int bs = row0 / H_;
+        h = row0 - bs * H_;
+        s = bs % S_;
+        const int dbs = stride / H_;
+        dh = stride - dbs * H_;
+        ds = dbs % S_;
+    }
+    __device__ __forceinline__ void advance() {
+        h += dh;
+        const int carry = h >= H ? 1 : 0;
+        h -= carry ? H : 0;
+        s += ds + carry;                      // < 2 S
+        s -= s >= S ? S : 0;
+    }
+};
 
 template <int VW>
 __global__ __launch_bounds__(NT) void rope_fwd_vec_kernel(const void* __restrict__ content, const void* __restrict__ xr,
@@ -384,9 +413,12 @@ __global__ __launch_bounds__(NT) void rope_fwd_vec_kernel(const void* __restrict
     const int jj = VW * j;
     const float* cosT = table + jj;
     const float* sinT = table + (long)S * half + jj;
-    for (int row = blockIdx.x * rpb + r_in; row < nrows; row += gridDim.x * rpb) {
+    // position s = (row / H) % S kept incrementally (the row advances by a launch constant): three divisions per
+    // thread instead of two per row — the kernel is bound by instruction issue, not by bytes
+    RopePos pos(blockIdx.x * rpb + r_in, gridDim.x * rpb, H, S);
+    for (int row = blockIdx.x * rpb + r_in; row < nrows; row += gridDim.x * rpb, pos.advance()) {
         const long o = (long)row * (dc + dr);
-        const int s = (row / H) % S;
+        const int s = pos.s;
         const vec c = ldf<VW>(cosT + s * half), sn = ldf<VW>(sinT + s * half);
         const vec x1 = ldtv<VW>(xr, (long)row * dr + jj, xr_type), x2 = ldtv<VW>(xr, (long)row * dr + jj + half, xr_type);
         for (int k = j; k < ic; k += ir)
@@ -414,9 +446,10 @@ __global__ __launch_bounds__(NT) void rope_bwd_vec_kernel(const void* __restrict
     const float* sinT = table + (long)S * half + jj;
     vec acc = vec(0.f);
     if (r_in < rpb) {
-        for (int row = blockIdx.x * rpb + r_in; row < nrows; row += gridDim.x * rpb) {
+        RopePos pos(blockIdx.x * rpb + r_in, gridDim.x * rpb, H, S);
+        for (int row = blockIdx.x * rpb + r_in; row < nrows; row += gridDim.x * rpb, pos.advance()) {
             const long go = (long)row * (dc + dr);
-            const int s = (row / H) % S;
+            const int s = pos.s;
             const vec c = ldf<VW>(cosT + s * half), sn = ldf<VW>(sinT + s * half);
             const vec g1 = ldtv<VW>(d_out, go + dc + jj, dout_type), g2 = ldtv<VW>(d_out, go + dc + jj + half, dout_type);
             const vec x1 = ldtv<VW>(xr, (long)row * dr + jj, xr_type), x2 = ldtv<VW>(xr, (long)row * dr + jj + half, xr_type);
@@ -431,8 +464,8 @@ __global__ __launch_bounds__(NT) void rope_bwd_vec_kernel(const void* __restrict
         if constexpr (VW == 1) {
             atomicAdd(&facc[jj], acc);
         } else {
-            atomicAdd(&facc[jj], acc[0]);
-            atomicAdd(&facc[jj + 1], acc[1]);
+#pragma unroll
+            for (int e = 0; e < VW; ++e) atomicAdd(&facc[jj + e], acc[e]);
         }
     }
     __syncthreads();
@@ -797,7 +830,10 @@ static bool st_ok(int t) { return t == CALM_ST_F32 || t == CALM_ST_BF16; }
 static bool rope_vec_ok(long nrows, int dr) {
     return CALM_ROPE_VEC && nrows < (1L << 31) - (1 << 22) && dr / 2 <= NT && dr / 2 <= ROPE_MAX_HALF;
 }
-static int rope_vw(int dc, int dr) { return ((dc & 1) == 0 && ((dr / 2) & 1) == 0) ? 2 : 1; }
+static int rope_vw(int dc, int dr) {     // widest column group that does not straddle the content / half boundaries
+    const int half = dr / 2;
+    return ((dc & 3) == 0 && (half & 3) == 0 && CALM_ROPE_VW4) ? 4 : ((dc & 1) == 0 && (half & 1) == 0) ? 2 : 1;
+}
 static int rope_vec_grid(long nrows, int dc, int dr) {
     const int rpb = NT / (dr / 2 / rope_vw(dc, dr));
     const long blocks = (nrows + rpb - 1) / rpb;
@@ -818,7 +854,10 @@ int calm_rope_fwd(const void* content, const void* xr, const float* inv_freq, fl
     const long nrows = (long)B * S * H;
     if (rope_vec_ok(nrows, dr)) {
         const dim3 gv(rope_vec_grid(nrows, dc, dr));
-        if (rope_vw(dc, dr) == 2)
+        if (rope_vw(dc, dr) == 4)
+            hipLaunchKernelGGL(rope_fwd_vec_kernel<4>, gv, dim3(NT), 0, as_stream(stream), content, xr, table, out,
+                               (int)nrows, S, H, dc, dr, content_type, xr_type, out_type);
+        else if (rope_vw(dc, dr) == 2)
             hipLaunchKernelGGL(rope_fwd_vec_kernel<2>, gv, dim3(NT), 0, as_stream(stream), content, xr, table, out,
                                (int)nrows, S, H, dc, dr, content_type, xr_type, out_type);
         else
@@ -849,7 +888,11 @@ int calm_rope_bwd(const void* d_out, const void* xr, const float* table, void* d
         // (A/B at S=80: 1024 -> 25 us, 2048 -> 36, 4096 -> 60), ~16 row passes per workgroup for large ones
         const int want = gv / 16;
         gv = want < CALM_ROPE_BWD_GRID ? (gv < CALM_ROPE_BWD_GRID ? gv : CALM_ROPE_BWD_GRID) : (want < 4096 ? want : 4096);
-        if (rope_vw(dc, dr) == 2)
+        if (rope_vw(dc, dr) == 4)
+            hipLaunchKernelGGL(rope_bwd_vec_kernel<4>, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table,
+                               d_content, d_xr, d_inv_freq, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type,
+                               dxr_type);
+        else if (rope_vw(dc, dr) == 2)
             hipLaunchKernelGGL(rope_bwd_vec_kernel<2>, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table,
                                d_content, d_xr, d_inv_freq, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type,
                                dxr_type);
