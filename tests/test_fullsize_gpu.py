@@ -71,6 +71,64 @@ def test_attention_forward_at_bench_size_properties():
     assert torch.equal(out1, out[:1]) and torch.equal(P1, P[:1])
 
 
+def test_bf16_attention_forward_backward_at_bench_size_properties():
+    """The bf16 pipeline's fused attention at BASELINE config #3's size (Base-224 stage 0, bs=256) through
+    size-independent properties: softmax rows sum to one (V = 1 -> out = 1), the raw QK^T and the mask against
+    library math on a slice, images independent (a single image gives the same bits), and — backward — the gradient
+    of a constant shift of all logits is zero (dM rows sum to ~0) and dV against library math on a slice."""
+    be = calm.backend.get_backend()
+    B, S, H, hd = 256, 224, 12, 56
+    D = H * hd
+    b16 = lambda t: t.bfloat16()
+    q, k, v = b16(g(B, S, D, seed=1, scale=0.3)), b16(g(B, S, D, seed=2, scale=0.3)), b16(g(B, S, D, seed=3))
+    w1, b1 = b16(g(2 * S, S, seed=4, scale=S ** -0.5)), g(2 * S, seed=5, scale=0.1)
+    w2, b2 = b16(g(S, 2 * S, seed=6, scale=(2 * S) ** -0.5)), g(S, seed=7, scale=0.1)
+    s1, s2 = torch.tensor([0.9], device="cuda"), torch.tensor([1.2], device="cuda")
+    e = lambda *s: torch.empty(*s, device="cuda", dtype=torch.bfloat16)
+    outs = lambda n: (e(n, S, D), e(n, S, S), e(n, S, 2 * S), e(n, S, 2 * S), e(n, S, S), e(n, S, S),
+                      torch.empty(n, H, S, device="cuda"))
+    out, R, hp, hg, Mk, MkT, lse = outs(B)
+    be.attn16_fwd(q, k, v, w1, b1, s1, w2, b2, s2, out, R, hp, hg, Mk, MkT, lse, B, S, H, hd)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
+    assert torch.equal(MkT, Mk.transpose(1, 2))
+    n = 3
+    Rref = torch.einsum("bid,bjd->bij", q[:n].float(), k[:n].float())
+    assert rel_err(R[:n].float(), Rref) < 2.0 ** -7                                   # one bf16 rounding of the result
+    mask = torch.nn.functional.gelu(R[:n].float() @ w1.float().T / 0.9 + b1) @ w2.float().T / 1.2 + b2
+    assert rel_err(Mk[:n].float(), mask) < 3e-2                                       # hidden + mask rounded to bf16
+    qh, kh, vh = (t[:n].float().view(n, S, H, hd).transpose(1, 2) for t in (q, k, v))
+    logits = qh @ kh.transpose(-1, -2) / math.sqrt(hd) + Mk[:n].float()[:, None]
+    ref = torch.softmax(logits, dim=-1) @ vh
+    assert rel_err(out[:n].float(), ref.transpose(1, 2).reshape(n, S, D)) < 3e-2
+    assert rel_err(lse[:n], torch.logsumexp(logits, dim=-1)) < 2e-3
+    # V = 1: every output element is a softmax row sum
+    ones = torch.ones_like(v)
+    o1 = outs(B)
+    be.attn16_fwd(q, k, ones, w1, b1, s1, w2, b2, s2, *o1, B, S, H, hd)
+    assert (o1[0].float() - 1.0).abs().max() < 2.0 ** -7
+    # images are independent: one image alone gives the same bits
+    oo = outs(1)
+    be.attn16_fwd(q[5:6], k[5:6], v[5:6], w1, b1, s1, w2, b2, s2, *oo, 1, S, H, hd)
+    assert torch.equal(oo[0], out[5:6]) and torch.equal(oo[4], Mk[5:6]) and torch.equal(oo[6], lse[5:6])
+    # backward
+    dout = b16(g(B, S, D, seed=8))
+    dq, dk, dv, dM = e(B, S, D), e(B, S, D), e(B, S, D), e(B * S, S)
+    delta = torch.empty(B, H, S, device="cuda")
+    be.attn16_bwd(q, k, v, out, dout, Mk, MkT, lse, delta, dq, dk, dv, dM, B, S, H, hd)
+    for t in (dq, dk, dv, dM):
+        assert torch.isfinite(t.float()).all()
+    # softmax is invariant to a shift of a logit row, so each row of dL/dlogits — and of its head sum dM — sums to 0
+    dMf = dM.float().view(B, S, S)
+    assert (dMf.sum(-1).abs().max() / dMf.abs().sum(-1).max()) < 2e-2
+    P = torch.softmax(logits, dim=-1)
+    dvr = (P.transpose(-1, -2) @ dout[:n].float().view(n, S, H, hd).transpose(1, 2)).transpose(1, 2).reshape(n, S, D)
+    assert rel_err(dv[:n].float(), dvr) < 3e-2
+    dq1, dk1, dv1, dM1 = e(1, S, D), e(1, S, D), e(1, S, D), e(S, S)
+    be.attn16_bwd(q[5:6], k[5:6], v[5:6], out[5:6], dout[5:6], Mk[5:6], MkT[5:6], lse[5:6],
+                  torch.empty(1, H, S, device="cuda"), dq1, dk1, dv1, dM1, 1, S, H, hd)
+    assert torch.equal(dq1, dq[5:6]) and torch.equal(dk1, dk[5:6]) and torch.equal(dv1, dv[5:6])
+
+
 def test_tokenisation_round_trips_at_bench_size():
     be = calm.backend.get_backend()
     B, S = 256, 224
