@@ -44,6 +44,45 @@ def test_large_linear_forward_dgrad_wgrad_against_library_matmul_and_linearity()
         assert torch.equal(outs[i], y)
 
 
+def test_bf16_pipeline_linears_at_bench_size():
+    """The bf16 pipeline's MLP products at Base-224 stage-0 size (57344 token rows): bf16 tensors in, bf16 out, fused
+    bias + GELU with the pre-activation saved, GELU' input gradient, split-K weight gradient — against fp32 library math
+    on the same (bf16-rounded) inputs.  Tolerances: one bf16 rounding of the result (2^-8 of the largest element, doubled);
+    exact for the additive structure (the vector epilogue and the one-element epilogue give the same bits)."""
+    be = calm.backend.get_backend()
+    calm.backend.set_matmul_precision("bf16")
+    try:
+        M, K, N = 57344, 672, 1344
+        b16 = lambda t: t.bfloat16()
+        x, w1, dy = b16(g(M, K, seed=1)), b16(g(N, K, seed=2, scale=K ** -0.5)), b16(g(M, N, seed=3))
+        bias, sigma = g(N, seed=4, scale=0.1), torch.tensor([1.3], device="cuda")
+        hp, hg = (torch.empty(M, N, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+        be.gemm(x, w1, hg, M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), inv_scale=sigma, bias=bias, act=1, C_pre=hp,
+                split_k=1)
+        z = (x.float() @ w1.float().T) / 1.3 + bias
+        assert rel_err(hp.float(), z) < 2.0 ** -7
+        assert rel_err(hg.float(), torch.nn.functional.gelu(z)) < 2.0 ** -7
+        # rows are independent: a slice of the rows alone gives the same bits (tile / epilogue mapping does not matter)
+        m2 = 3000
+        hp2, hg2 = (torch.empty(m2, N, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+        be.gemm(x[:m2], w1, hg2, m2, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), inv_scale=sigma, bias=bias, act=1,
+                C_pre=hp2, split_k=1)
+        assert torch.equal(hp2, hp[:m2]) and torch.equal(hg2, hg[:m2])
+        # input gradient through GELU': dz = (dy W2ᵀ... here: dy [M,N] times w1 [N,K]) is a plain product; GELU' needs aux
+        dz = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+        w2 = b16(g(N, N, seed=5, scale=N ** -0.5))
+        be.gemm(dy, w2, dz, M, N, N, (N, 1, 0, 0), (1, N, 0, 0), (N, 0, 0), inv_scale=sigma, act=2, aux=hp, split_k=1)
+        zz = hp.float().requires_grad_(True)
+        torch.nn.functional.gelu(zz).backward((dy.float() @ w2.float()) / 1.3)
+        assert rel_err(dz.float(), zz.grad) < 2.0 ** -7
+        # weight gradient over 57344 tokens (split-K, fp32 output)
+        G = torch.zeros(N, K, device="cuda")
+        be.gemm(dy, x, G, N, K, M, (1, N, 0, 0), (1, K, 0, 0), (K, 0, 0))
+        assert rel_err(G, dy.float().T @ x.float()) < 1e-4
+    finally:
+        calm.backend.set_matmul_precision("fp32")
+
+
 def test_attention_forward_at_bench_size_properties():
     be = calm.backend.get_backend()
     B, S, H, hd = 256, 224, 6, 112
