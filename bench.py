@@ -171,6 +171,12 @@ class AttentionProfiler:
                 "largest_tflops": big[0] / (1e-3 * sum(r[1].elapsed_time(r[2]) for r in same) / len(same)) / 1e12}
 
 
+# kernel-name prefixes of the GEMM families in the rocprofv3 summaries (tests/test_host_logic_cpu.py checks that the
+# committed summaries still have rows under them: a renamed kernel or namespace silently turned `traffic` into null)
+GEMM_PMC_PREFIX = {"fp32": "calm_gemm_detail::gemm_f32", "bf16": "calm_gemm_detail::gemm_bf16"}
+ATTN_PMC_PREFIX = {"fp32": "attn_fwd_kernel", "bf16": "attn16_fwd_kernel"}
+
+
 def pmc_rows(kernel_prefix):
     """(rows, source, stale) of the newest committed rocprofv3 PMC summary for kernels starting with `kernel_prefix`.
     The summary carries a stamp (scripts/pmc_summary.py: sha256 of the kernel sources it was measured with); `stale` is
@@ -374,7 +380,7 @@ def main():
                         "gemm_ms_per_step": round(ms / args.prof_steps, 2),
                         "algorithmic_gflop_per_step": round(flops / args.prof_steps / 1e9, 1)}
             # HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate passes) from the committed summary
-            detail = pmc_traffic("gemm_f32_kernel" if args.precision == "fp32" else "calm_gemm_detail::gemm_bf16")
+            detail = pmc_traffic(GEMM_PMC_PREFIX["fp32" if args.precision == "fp32" else "bf16"])
             if detail is not None:
                 roofline["traffic"] = detail["hbm_bytes_per_launch"]
                 roofline["traffic_detail"] = detail

@@ -210,3 +210,22 @@ def test_residual_state_manager_modes_match_the_oracle_restatement(mode):
             b = st.merge(zq, zkv, mq, sq, mk, sk)
             assert torch.allclose(a[0], b[0], atol=1e-6) and torch.allclose(a[1], b[1], atol=1e-6)
     assert abs(float(sm.get_kl_loss()) - float(st.kl_loss())) < 1e-6
+
+
+def test_bench_finds_its_kernels_in_the_committed_pmc_summaries():
+    """bench.py reads HBM traffic / MFMA utilisation of the dominant kernels from the committed rocprofv3 PMC summaries
+    by kernel-name prefix: every prefix it uses must still name rows there (a renamed kernel would silently turn the
+    `traffic` field of the bench line into null), and each summary must carry its source stamp."""
+    import glob
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    for prefix in list(bench.GEMM_PMC_PREFIX.values()) + list(bench.ATTN_PMC_PREFIX.values()):
+        rows, source, stale = bench.pmc_rows(prefix)
+        assert rows and source, prefix
+        assert source.startswith("profiles/round2_"), (prefix, source)
+        assert stale in (True, False)
+    for f in glob.glob(os.path.join(root, "profiles", "round2_*pmc_summary.csv")):
+        assert os.path.exists(f + ".stamp.json"), f
