@@ -134,12 +134,12 @@ def test_bf16_attention_forward_backward_at_bench_size_properties():
     Rref = torch.einsum("bid,bjd->bij", q[:n].float(), k[:n].float())
     assert rel_err(R[:n].float(), Rref) < 2.0 ** -7                                   # one bf16 rounding of the result
     mask = torch.nn.functional.gelu(R[:n].float() @ w1.float().T / 0.9 + b1) @ w2.float().T / 1.2 + b2
-    assert rel_err(Mk[:n].float(), mask) < 3e-2                                       # hidden + mask rounded to bf16
+    assert rel_err(Mk[:n].float(), mask) < 1e-2                                       # hidden + mask rounded to bf16 (measured 2.8e-3)
     qh, kh, vh = (t[:n].float().view(n, S, H, hd).transpose(1, 2) for t in (q, k, v))
     logits = qh @ kh.transpose(-1, -2) / math.sqrt(hd) + Mk[:n].float()[:, None]
     ref = torch.softmax(logits, dim=-1) @ vh
-    assert rel_err(out[:n].float(), ref.transpose(1, 2).reshape(n, S, D)) < 3e-2
-    assert rel_err(lse[:n], torch.logsumexp(logits, dim=-1)) < 2e-3
+    assert rel_err(out[:n].float(), ref.transpose(1, 2).reshape(n, S, D)) < 1e-2       # measured 3.4e-3
+    assert rel_err(lse[:n], torch.logsumexp(logits, dim=-1)) < 1e-4
     # V = 1: every output element is a softmax row sum
     ones = torch.ones_like(v)
     o1 = outs(B)
@@ -158,10 +158,10 @@ def test_bf16_attention_forward_backward_at_bench_size_properties():
         assert torch.isfinite(t.float()).all()
     # softmax is invariant to a shift of a logit row, so each row of dL/dlogits — and of its head sum dM — sums to 0
     dMf = dM.float().view(B, S, S)
-    assert (dMf.sum(-1).abs().max() / dMf.abs().sum(-1).max()) < 2e-2
+    assert (dMf.sum(-1).abs().max() / dMf.abs().sum(-1).max()) < 1e-2                 # measured 3.3e-3
     P = torch.softmax(logits, dim=-1)
     dvr = (P.transpose(-1, -2) @ dout[:n].float().view(n, S, H, hd).transpose(1, 2)).transpose(1, 2).reshape(n, S, D)
-    assert rel_err(dv[:n].float(), dvr) < 3e-2
+    assert rel_err(dv[:n].float(), dvr) < 1e-2                                          # measured 2.8e-3
     dq1, dk1, dv1, dM1 = e(1, S, D), e(1, S, D), e(1, S, D), e(S, S)
     be.attn16_bwd(q[5:6], k[5:6], v[5:6], out[5:6], dout[5:6], Mk[5:6], MkT[5:6], lse[5:6],
                   torch.empty(1, H, S, device="cuda"), dq1, dk1, dv1, dM1, 1, S, H, hd)
