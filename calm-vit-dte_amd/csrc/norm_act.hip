@@ -342,7 +342,7 @@ __global__ __launch_bounds__(NT) void rope_bwd_kernel(const void* __restrict__ d
 template <int VW> struct RopeVec { typedef float type __attribute__((ext_vector_type(VW))); };
 template <> struct RopeVec<1> { typedef float type; };
 template <int VW>
-__device__ __forceinline__ typename RopeVec<VW>::type ldtv(const void* p, long i, int type) {
+__device__ __forceinline__ typename RopeVec<VW>::type ldtv(const void* p, unsigned i, int type) {
     if constexpr (VW == 1) {
         return ldt(p, i, type);
     } else {
@@ -359,7 +359,7 @@ __device__ __forceinline__ typename RopeVec<VW>::type ldtv(const void* p, long i
     }
 }
 template <int VW>
-__device__ __forceinline__ void sttv(void* p, long i, typename RopeVec<VW>::type v, int type) {
+__device__ __forceinline__ void sttv(void* p, unsigned i, typename RopeVec<VW>::type v, int type) {
     if constexpr (VW == 1) {
         stt(p, i, v, type);
     } else {
@@ -416,13 +416,15 @@ __global__ __launch_bounds__(NT) void rope_fwd_vec_kernel(const void* __restrict
     // position s = (row / H) % S kept incrementally (the row advances by a launch constant): three divisions per
     // thread instead of two per row — the kernel is bound by instruction issue, not by bytes
     RopePos pos(blockIdx.x * rpb + r_in, gridDim.x * rpb, H, S);
+    // element offsets as 32-bit unsigned values from the (uniform) tensor bases: the loads and stores then take the
+    // scalar-base + 32-bit-offset form instead of a 64-bit multiply-add per access (host: every tensor < 2^31 elements)
     for (int row = blockIdx.x * rpb + r_in; row < nrows; row += gridDim.x * rpb, pos.advance()) {
-        const long o = (long)row * (dc + dr);
+        const unsigned o = (unsigned)row * (unsigned)(dc + dr), xo = (unsigned)row * (unsigned)dr + jj;
         const int s = pos.s;
         const vec c = ldf<VW>(cosT + s * half), sn = ldf<VW>(sinT + s * half);
-        const vec x1 = ldtv<VW>(xr, (long)row * dr + jj, xr_type), x2 = ldtv<VW>(xr, (long)row * dr + jj + half, xr_type);
+        const vec x1 = ldtv<VW>(xr, xo, xr_type), x2 = ldtv<VW>(xr, xo + half, xr_type);
         for (int k = j; k < ic; k += ir)
-            sttv<VW>(out, o + VW * k, ldtv<VW>(content, (long)row * dc + VW * k, content_type), out_type);
+            sttv<VW>(out, o + VW * k, ldtv<VW>(content, (unsigned)row * (unsigned)dc + VW * k, content_type), out_type);
         sttv<VW>(out, o + dc + jj, x1 * c - x2 * sn, out_type);
         sttv<VW>(out, o + dc + jj + half, x2 * c + x1 * sn, out_type);
     }
@@ -448,15 +450,15 @@ __global__ __launch_bounds__(NT) void rope_bwd_vec_kernel(const void* __restrict
     if (r_in < rpb) {
         RopePos pos(blockIdx.x * rpb + r_in, gridDim.x * rpb, H, S);
         for (int row = blockIdx.x * rpb + r_in; row < nrows; row += gridDim.x * rpb, pos.advance()) {
-            const long go = (long)row * (dc + dr);
+            const unsigned go = (unsigned)row * (unsigned)(dc + dr), xo = (unsigned)row * (unsigned)dr + jj;
             const int s = pos.s;
             const vec c = ldf<VW>(cosT + s * half), sn = ldf<VW>(sinT + s * half);
             const vec g1 = ldtv<VW>(d_out, go + dc + jj, dout_type), g2 = ldtv<VW>(d_out, go + dc + jj + half, dout_type);
-            const vec x1 = ldtv<VW>(xr, (long)row * dr + jj, xr_type), x2 = ldtv<VW>(xr, (long)row * dr + jj + half, xr_type);
+            const vec x1 = ldtv<VW>(xr, xo, xr_type), x2 = ldtv<VW>(xr, xo + half, xr_type);
             for (int k = j; k < ic; k += ir)
-                sttv<VW>(d_content, (long)row * dc + VW * k, ldtv<VW>(d_out, go + VW * k, dout_type), dcontent_type);
-            sttv<VW>(d_xr, (long)row * dr + jj, g1 * c + g2 * sn, dxr_type);
-            sttv<VW>(d_xr, (long)row * dr + jj + half, g2 * c - g1 * sn, dxr_type);
+                sttv<VW>(d_content, (unsigned)row * (unsigned)dc + VW * k, ldtv<VW>(d_out, go + VW * k, dout_type), dcontent_type);
+            sttv<VW>(d_xr, xo, g1 * c + g2 * sn, dxr_type);
+            sttv<VW>(d_xr, xo + half, g2 * c - g1 * sn, dxr_type);
             // d/d(angle): y1 = x1 c - x2 s, y2 = x2 c + x1 s ; angle = s * inv_freq[jj]
             const vec dang = g1 * (-x1 * sn - x2 * c) + g2 * (-x2 * sn + x1 * c);
             acc += dang * (float)s;
@@ -827,8 +829,8 @@ int calm_layernorm_bwd(const void* dy, const float* x, const float* w, const flo
 
 static bool st_ok(int t) { return t == CALM_ST_F32 || t == CALM_ST_BF16; }
 // row-walking RoPE kernels: 32-bit row index; VW = 2 when column pairs do not straddle the content / half boundaries
-static bool rope_vec_ok(long nrows, int dr) {
-    return CALM_ROPE_VEC && nrows < (1L << 31) - (1 << 22) && dr / 2 <= NT && dr / 2 <= ROPE_MAX_HALF;
+static bool rope_vec_ok(long nrows, int dc, int dr) {
+    return CALM_ROPE_VEC && nrows * (dc + dr) < (1L << 31) && dr / 2 <= NT && dr / 2 <= ROPE_MAX_HALF;      // 32-bit element offsets
 }
 static int rope_vw(int dc, int dr) {     // widest column group that does not straddle the content / half boundaries
     const int half = dr / 2;
@@ -852,7 +854,7 @@ int calm_rope_fwd(const void* content, const void* xr, const float* inv_freq, fl
                        table, S, half);
     CALM_LAUNCH_CHECK();
     const long nrows = (long)B * S * H;
-    if (rope_vec_ok(nrows, dr)) {
+    if (rope_vec_ok(nrows, dc, dr)) {
         const dim3 gv(rope_vec_grid(nrows, dc, dr));
         if (rope_vw(dc, dr) == 4)
             hipLaunchKernelGGL(rope_fwd_vec_kernel<4>, gv, dim3(NT), 0, as_stream(stream), content, xr, table, out,
@@ -882,7 +884,7 @@ int calm_rope_bwd(const void* d_out, const void* xr, const float* table, void* d
     if (!st_ok(dout_type) || !st_ok(xr_type) || !st_ok(dcontent_type) || !st_ok(dxr_type)) return CALM_E_INVAL;
     if (dr / 2 > ROPE_MAX_HALF) return CALM_E_UNSUPP;
     const long nrows = (long)B * S * H;
-    if (rope_vec_ok(nrows, dr)) {
+    if (rope_vec_ok(nrows, dc, dr)) {
         int gv = rope_vec_grid(nrows, dc, dr);
         // every workgroup ends with dr/2 atomics on one cache line of d_inv_freq: few workgroups for small launches
         // (A/B at S=80: 1024 -> 25 us, 2048 -> 36, 4096 -> 60), ~16 row passes per workgroup for large ones
