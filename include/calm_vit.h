@@ -273,7 +273,8 @@ int calm_sn_power_iter(const void* plan_dev, const calm_sn_plan_info* info, int3
  * once per forward (W_orig itself, not W_orig/sigma: the GEMM epilogues keep dividing by sigma in fp32), next to the
  * power iteration.  entries_dev: table in device memory; work items are chunks of calm_cast_chunk_elems() consecutive
  * elements of one entry: chunk_entry_dev[k] = entry of chunk k, entry.chunk0 = its first chunk.  Round to nearest even
- * (what autocast's weight cast does, torch `.to(bfloat16)`).
+ * (what autocast's weight cast does inside `with autocast(device_type="cuda", dtype=torch.bfloat16)`,
+ * distributed_trainer_cls.py:84-85: torch `.to(bfloat16)` of every Linear weight per forward).
  * ------------------------------------------------------------------------------------- */
 typedef struct calm_cast_entry {
     const float* src;
