@@ -128,6 +128,12 @@ struct BlockStage {
 
 // NP = pairs of 16-key tiles (keys padded to 32 NP), HDP = head dim padded to 32
 // two workgroups share a CU (one's load / barrier stalls under the other's MFMAs) when both fit at 3 waves per SIMD
+#ifndef ATT16_BWDQ_PRE_MAX
+#define ATT16_BWDQ_PRE_MAX 448     // query-side backward: next head's K_h / V_h prefetched into registers up to this NP x HDP
+#endif
+#ifndef ATT16_BWDKV_PRE_MAX
+#define ATT16_BWDKV_PRE_MAX 448
+#endif
 #ifndef ATT16_FWD_OCC3
 #define ATT16_FWD_OCC3 0     // A/B'd: constraining the registers for a second workgroup per CU spills (S=176: 367 vs 240 us)
 #endif
@@ -517,9 +523,10 @@ __global__ __launch_bounds__(64 * waves_for(NP)) void attn16_bwd_q_kernel(const 
 #pragma unroll
     for (int t = 0; t < NJ; ++t) accM[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
     // one chunk per head (all keys resident): the NEXT head's K_h / V_h are fetched into registers under this head's math
-    // (only where the prefetch registers fit beside the 8 NP mask-gradient accumulators without spilling: NP x HDP <= 256)
+    // (up to NP x HDP = 448 — the stages of Base-224: beyond 256 the prefetch registers spill (156-184 bytes of scratch per
+    // lane), which still pays: the spilled vectors sit in L1 / L2 when the next head needs them, S=176 -6.6 %, S=224 -3.8 %)
     constexpr int NTHB = 64 * waves_for(NP);
-    constexpr bool PRE = bwd_chunk_pairs_c(NP, HDP) == NP && NP * HDP <= 256;
+    constexpr bool PRE = bwd_chunk_pairs_c(NP, HDP) == NP && NP * HDP <= ATT16_BWDQ_PRE_MAX;
     constexpr int NVB = PRE ? (32 * NP * HDP / 4 + NTHB - 1) / NTHB : 1;
     constexpr bool pre = PRE;
     BlockStage<NVB, NTHB> sa, sb;
@@ -636,7 +643,7 @@ __global__ __launch_bounds__(64 * waves_for(NP)) void attn16_bwd_kv_kernel(const
     const __bf16* Mcol = p.MkT + ((long)b * S + k_ld) * S;
     const bf16x4 zero4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
     constexpr int NTHB = 64 * waves_for(NP);
-    constexpr bool PRE = bwd_chunk_pairs_c(NP, HDP) == NP && NP * HDP <= 448;      // see the query-side kernel
+    constexpr bool PRE = bwd_chunk_pairs_c(NP, HDP) == NP && NP * HDP <= ATT16_BWDKV_PRE_MAX;      // see the query-side kernel
     constexpr int NVB = PRE ? (32 * NP * HDP / 4 + NTHB - 1) / NTHB : 1;
     constexpr bool pre = PRE;
     BlockStage<NVB, NTHB> sa, sb;
