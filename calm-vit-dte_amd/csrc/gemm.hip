@@ -2,6 +2,7 @@
 // Two kernel families share tiling, remap, split logic and epilogue (gemm_common.h): the exact fp32 MFMA family
 // (gemm_f32.hip) and the bf16-operand family (gemm_bf16.hip).
 #include "gemm_common.h"
+#include <stdlib.h>
 
 using namespace calm_gemm_detail;
 
@@ -40,6 +41,154 @@ inline bool mult4(int64_t x) { return (x & 3) == 0; }
 #define CALM_GEMM_WS_MIN_SLICES 48     // per-slice partial tiles + one reduction instead of atomics from this many k-slices
 #endif                                 // per output (A/B with plain stores in place of the atomics: outputs of 528 rows and
                                        // more, <= 42 slices, do not change; 384x768 ... 240x240, 53-106 slices, -15..-30%)
+
+
+// ---- pipelined persistent family (gemm_bf16p.h) -----------------------------------------------------------------------
+// Takes the launches whose operands are both bf16 tensors: activation x weight (forward), gradient x weight^T (data
+// gradient), gradient^T x activation (weight gradient, k-split over the chip), plain batches and independent groups.
+// Declines (the 256-thread / 256x128 kernels keep them): batch-reduced and group-reduced sums, scalar epilogues, tiny
+// problems.  CALM_GEMM_PIPE=0 in the environment switches the family off (A/B runs).
+constexpr int PIPE_DECLINED = -1000;
+
+static bool pipe_enabled() {
+    static const int on = [] {
+        const char* e = getenv("CALM_GEMM_PIPE");
+        return (e && e[0] == '0') ? 0 : 1;
+    }();
+    return on != 0;
+}
+
+// modelled duration of a launch (cycles of one CU, up to a common factor): `rounds` items per persistent workgroup, each
+// nk k-tiles of a (64 mt) x (32 nt) tile; a k-tile is bound by its MFMAs (64 mt nt cycles per SIMD at two waves) or by
+// staging its (64 mt + 32 nt) x 128 bytes at ~40 B per cycle; the epilogue costs about one extra k-tile per tile row set
+static double pipe_cost(long items, int mt, int nt, int nk, bool split) {
+    const long rounds = (items + 255) / 256;
+    const double mfma = 64.0 * mt * nt, stage = (64.0 * mt + 32.0 * nt) * 128.0 / 40.0;
+    const double ktile = (mfma > stage ? mfma : stage) + 120.0;
+    const double epi = (split ? 90.0 : 45.0) * mt * nt + 600.0;
+    return rounds * (nk * ktile + epi);
+}
+
+static int pipe_run(const calm_gemm_args* a, GemmP& p, bool akc, bool bkc, hipStream_t s, int64_t* query) {
+    if (!akc && bkc) return PIPE_DECLINED;                      // row-contiguous A with k-contiguous B: not instantiated
+    if (a->reduce_batch || !p.epi_vec) return PIPE_DECLINED;
+    if ((a->act == CALM_ACT_GELU_BWD) + (a->residual != nullptr) + (a->accumulate != 0) > 1) return PIPE_DECLINED;   // one C-shaped epilogue operand
+    if (a->M < 128 || a->N < 64 || a->K < 64) return PIPE_DECLINED;
+    const int batch = a->batch0 * a->batch1;
+    // per-lane staging offsets are 32-bit byte offsets from the batch entry's base
+    const int64_t span_a = akc ? (int64_t)a->M * a->a_rs : 64 * a->a_cs + a->M;
+    const int64_t span_b = bkc ? (int64_t)a->N * a->b_rs : 64 * a->b_cs + a->N;
+    if (span_a >= (1ll << 30) || span_b >= (1ll << 30)) return PIPE_DECLINED;
+    if ((int64_t)a->M * a->c_rs >= (1ll << 29)) return PIPE_DECLINED;        // the epilogue's 32-bit byte offsets into C
+    const bool trivial_epi = !a->bias && !a->col_scale && !a->residual && !a->C_pre && a->act == CALM_ACT_NONE;
+    const int kpb = (a->K + 63) / 64;
+
+    // k-split: the same decisions as the 256-thread families (weight gradients: one problem, or independent groups,
+    // whose tiles alone cannot fill the chip)
+    const int tiles_min = ((a->M + 255) / 256) * ((a->N + 255) / 256);
+    const bool group_split = a->n_group && a->split_k == 0 && trivial_epi && a->C_group[0] && tiles_min * batch < 128 && kpb >= 32;
+    const bool k_split = group_split || a->split_k > 1 ||
+                         (a->split_k == 0 && batch == 1 && trivial_epi && tiles_min < 128 && kpb >= 32);
+    if (k_split && !group_split && batch != 1) return PIPE_DECLINED;
+    if (k_split && (!trivial_epi || a->c_type != CALM_ST_F32)) return PIPE_DECLINED;
+
+    int best_mt = 0, best_nt = 0, best_split = 1;
+    double best = 1e300;
+    for (int mt = 2; mt <= 4; ++mt)
+        for (int nt = 4; nt <= 8; ++nt) {
+            const long tiles = (long)((a->M + 64 * mt - 1) / (64 * mt)) * ((a->N + 32 * nt - 1) / (32 * nt));
+            if (!k_split) {
+                const double c = pipe_cost(tiles * batch, mt, nt, kpb, false);
+                if (c < best) { best = c; best_mt = mt; best_nt = nt; best_split = 1; }
+                continue;
+            }
+            const long per = tiles * (group_split ? batch : 1);
+            for (int rounds = 1; rounds <= 4; ++rounds) {
+                int ns = a->split_k > 1 ? a->split_k : (int)(256L * rounds / per);
+                if (ns < 1) ns = 1;
+                if (ns > kpb / 4) ns = kpb / 4 > 0 ? kpb / 4 : 1;
+                const int nk = (kpb + ns - 1) / ns;
+                ns = (kpb + nk - 1) / nk;
+                // the slices' partial tiles are combined through atomics / the workspace: M x N x 4 bytes each at ~1 TB/s
+                const double comb = ns > 1 ? (double)a->M * a->N * 4.0 * ns * (group_split ? batch : 1) / 1.0e12 * 2.0e9 / 256.0 : 0.0;
+                const double c = pipe_cost(per * ns, mt, nt, nk, ns > 1) + comb;
+                if (c < best) { best = c; best_mt = mt; best_nt = nt; best_split = ns; }
+            }
+        }
+    const int mt = best_mt, nt = best_nt, nsplit = best_split;
+    p.tiles_m = (a->M + 64 * mt - 1) / (64 * mt);
+    p.tiles_n = (a->N + 32 * nt - 1) / (32 * nt);
+    p.kpb = kpb;
+    p.kb_total = kpb;
+    p.reduce_group = 0;
+    p.atomic = nsplit > 1;
+    p.slices_per_batch = 0;
+    if (p.atomic) {
+        p.kb_per_z = (kpb + nsplit - 1) / nsplit;
+        const int ns = (kpb + p.kb_per_z - 1) / p.kb_per_z;
+        if (group_split) {
+            p.slices_per_batch = ns;
+            p.nz = ns * batch;
+        } else {
+            p.nz = ns;
+        }
+    } else {
+        p.kb_per_z = kpb;
+        p.nz = batch;
+    }
+    const int n_out = p.slices_per_batch ? batch : 1;
+    const int slices_per_out = p.atomic ? p.nz / n_out : 1;
+    p.ws = nullptr;
+    p.ws_slice = (long)a->M * a->N;
+    int64_t ws_need = 0;
+    if (p.atomic && slices_per_out >= CALM_GEMM_WS_MIN_SLICES && p.ws_slice >= 100000)
+        ws_need = (int64_t)sizeof(float) * p.nz * p.ws_slice;
+    if (query) {
+        *query = ws_need;
+        return 0;
+    }
+    const bool use_ws = ws_need > 0 && a->workspace && a->workspace_bytes >= ws_need && aligned16(a->workspace);
+    if (use_ws) {
+        p.ws = (float*)a->workspace;
+    } else if (p.atomic && !a->accumulate) {
+        for (int g = 0; g < n_out; ++g) {
+            float* out = (float*)(p.slices_per_batch ? p.Cg[g] : p.C);
+            hipError_t e;
+            if (a->c_rs == a->N) e = hipMemsetAsync(out, 0, sizeof(float) * (size_t)a->M * a->N, s);
+            else e = hipMemset2DAsync(out, sizeof(float) * a->c_rs, 0, sizeof(float) * a->N, a->M, s);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+#ifdef CALM_PIPE_STAMP
+    if (!p.atomic && a->workspace && a->workspace_bytes >= 256 * 2 * 8 * 4 * 8) p.ws = (float*)a->workspace;   // diagnostic build: stamps
+#endif
+    const long items = (long)p.tiles_m * p.tiles_n * p.nz;
+    const int grid = (int)(items < 256 ? items : 256);
+    static const int stagger = [] { const char* e = getenv("CALM_PIPE_STAGGER"); return e ? atoi(e) : 0; }();
+    p.stagger = items > 256 ? stagger : 0;
+    {   // 8 columns per lane in the epilogue when every tensor it touches is bf16 and addressable in aligned groups of 8
+        auto m8 = [](int64_t x) { return (x & 7) == 0; };
+        const bool u8 = !p.atomic && a->c_type == CALM_ST_BF16 && (!a->aux || a->aux_type == CALM_ST_BF16) &&
+                        (!a->residual || (a->r_type == CALM_ST_BF16 && m8(a->r_rs) && m8(a->r_b0) && m8(a->r_b1))) &&
+                        m8(a->N) && m8(a->c_rs) && m8(a->c_b0) && m8(a->c_b1);
+        p.epi_unit = u8 ? 8 : 4;
+    }
+    int rc;
+    if (akc && bkc) rc = launch_pipe_kk(p, mt, nt, grid, s);
+    else if (akc) rc = launch_pipe_km(p, mt, nt, grid, s);
+    else rc = launch_pipe_mm(p, mt, nt, grid, s);
+    if (rc || !use_ws) return rc;
+    ReduceP q;
+    q.ws = p.ws; q.ws_slice = p.ws_slice; q.nslices = slices_per_out;
+    q.C = (float*)p.C; q.c_b0 = a->c_b0; q.c_rs = a->c_rs;
+    for (int g = 0; g < 4; ++g) q.Cg[g] = p.slices_per_batch ? (float*)p.Cg[g] : nullptr;
+    q.M = a->M; q.N = a->N; q.accumulate = a->accumulate;
+    const long total = (long)a->M * a->N;
+    const int gx = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(splitk_reduce, dim3(gx, n_out), dim3(256), 0, s, q);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
 
 // query != nullptr: plan only and report the workspace size of the launch (calm_gemm_workspace_bytes)
 static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
@@ -135,6 +284,10 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
     // only read fp32 tensors: a bf16 tensor in a launch that cannot be vectorised is the caller's layout error
     if (!vec && any_bf16_tensor) return CALM_E_LAYOUT;
     const int family = vec ? a->dtype : CALM_F32;
+    if (family == CALM_BF16 && a->a_type == CALM_ST_BF16 && a->b_type == CALM_ST_BF16 && pipe_enabled()) {
+        const int rc = pipe_run(a, p, akc, bkc, s, query);
+        if (rc != PIPE_DECLINED) return rc;
+    }
     const int bk = family == CALM_F32 ? BK : CK;
     p.kpb = (a->K + bk - 1) / bk;
     const bool trivial_epi = !a->bias && !a->col_scale && !a->residual && !a->C_pre && a->act == CALM_ACT_NONE;

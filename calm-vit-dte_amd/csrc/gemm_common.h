@@ -63,6 +63,9 @@ struct GemmP {
     int a_type, b_type, c_type, aux_type, r_type;      // CALM_ST_*: only the bf16-operand family takes bf16 tensors
     const float* dq_a; const float* dq_b;              // fp8 operands: device dequantisation factors (amax / FP8_MAX)
     int epi_vec;    // every epilogue tensor is addressable in aligned groups of 4 columns (dispatcher): vector epilogue
+    int nz;         // pipelined family (gemm_bf16p.h): batch entries / k-slices per tile = work items per tile
+    int stagger;    // experiment: start delay step of the persistent workgroups
+    int epi_unit;   // pipelined family: columns per lane in the row-layout epilogue (8: every epilogue tensor is bf16)
 };
 
 // operand base of batch entry (b0, b1); T = the operand's storage type
@@ -331,5 +334,10 @@ int launch_f32(const GemmP& p, dim3 grid, int bn, bool akc, bool bkc, bool vec, 
 int launch_bf16(const GemmP& p, dim3 grid, int bn, bool akc, bool bkc, int npass, hipStream_t s);
 int launch_bf16_wide(const GemmP& p, dim3 grid, bool akc, bool bkc, hipStream_t s);
 int launch_fp8(const GemmP& p, dim3 grid, hipStream_t s);           // gemm_fp8.hip
+// pipelined persistent bf16-tensor family (gemm_bf16p.h), one translation unit per operand-layout pair:
+// kk = A, B k-contiguous; km = A k-contiguous, B row-contiguous; mm = both row-contiguous.  tile (64 mt) x (32 nt)
+int launch_pipe_kk(const GemmP& p, int mt, int nt, int grid, hipStream_t s);
+int launch_pipe_km(const GemmP& p, int mt, int nt, int grid, hipStream_t s);
+int launch_pipe_mm(const GemmP& p, int mt, int nt, int grid, hipStream_t s);
 
 }  // namespace calm_gemm_detail
