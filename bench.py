@@ -218,12 +218,36 @@ def pmc_traffic(kernel_prefix):
             "source": source, "stale": stale}
 
 
-def cpu_baseline(wl, budget_s=15.0):
-    """CPU oracle (port of the reference path) fwd+bwd+AdamW on a bounded sample of the workload."""
+def host_cpu_info():
+    """(cpu model, physical cores inside this process's affinity mask, logical CPUs in the mask) from /proc/cpuinfo."""
+    aff = sorted(os.sched_getaffinity(0))
+    model, cores, cur = "unknown", set(), {}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if ":" in line:
+                k, v = (t.strip() for t in line.split(":", 1))
+                cur[k] = v
+            elif cur:
+                if int(cur.get("processor", -1)) in aff:
+                    cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+                    model = cur.get("model name", model)
+                cur = {}
+        if cur and int(cur.get("processor", -1)) in aff:
+            cores.add((cur.get("physical id", "0"), cur.get("core id", cur.get("processor"))))
+            model = cur.get("model name", model)
+    except OSError:
+        pass
+    return model, max(1, len(cores) or len(aff)), len(aff)
+
+
+def cpu_baseline(wl, budget_s=30.0):
+    """CPU oracle (port of the reference path) fwd+bwd+AdamW on a bounded sample of the workload, as BASELINE.md
+    section 3 prescribes: fp32, one thread per PHYSICAL core of the affinity mask (never more: oversubscription cost 20x
+    in the survey), bs = 8, 2 warm-up + >= 5 timed steps, median."""
     from oracle import calm_oracle as O
     import calm_vit_dte_amd as calm
     W = calm.synthetic_weights
-    threads = max(1, min(len(os.sched_getaffinity(0)), 16))
+    cpu_model, threads, logical = host_cpu_info()
     torch.set_num_threads(threads)
     cfg = O.ViTConfig(force_reduce=False, generate=False, **wl["kw"])
     P = {k: torch.from_numpy(v) for k, v in W.make_params(O.vit_param_shapes(cfg), WEIGHT_SEED).items()}
@@ -233,7 +257,7 @@ def cpu_baseline(wl, budget_s=15.0):
             P[k].requires_grad_(True)
             leaves.append(P[k])
     opt = torch.optim.AdamW(leaves, lr=3.1e-3, weight_decay=0.02, betas=(0.9, 0.98))
-    bs = 4 if cfg.seq_length >= 128 else 32
+    bs = 8 if cfg.seq_length >= 128 else 32
     x, y = synthetic_batch(bs, cfg.seq_length, cfg.out_features, 0, "cpu")
 
     def step():
@@ -244,15 +268,18 @@ def cpu_baseline(wl, budget_s=15.0):
         opt.step()
         opt.zero_grad()
 
-    step()                                           # warm-up (also converges nothing: timing only)
+    step()
+    step()                                           # 2 warm-up steps (timing only)
     times, t_start = [], time.perf_counter()
-    while len(times) < 24 and (time.perf_counter() - t_start) < budget_s:      # about 10-25 s of CPU work
+    while len(times) < 5 or (len(times) < 16 and (time.perf_counter() - t_start) < budget_s):
         t0 = time.perf_counter()
         step()
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    return {"value": round(bs / med, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": f"oracle fwd+bwd+AdamW fp32, bs={bs}, {len(times)} timed steps after 1 warm-up, median"}
+    return {"value": round(bs / med, 3), "unit": "images/sec", "cores": threads, "affinity": logical, "cpu_model": cpu_model,
+            "kind": "port",
+            "sample": f"oracle fwd+bwd+AdamW fp32, bs={bs}, {len(times)} timed steps after 2 warm-up, median; "
+                      f"{threads} threads = physical cores of the {logical}-CPU affinity mask"}
 
 
 def self_launch(n):
@@ -292,6 +319,8 @@ def main():
                     help="the reference trainer's call pattern (cls:84-95): forward under torch.autocast(bfloat16), "
                          "loss scaled by a torch GradScaler — the GEMMs then run on the bf16 pipe as with --precision bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the Base-224 autocast measurement that the default (small224 fp32) run attaches as 'secondary'")
     ap.add_argument("--gemm-report", default="", help="write a per-shape GEMM table (csv) from the profiled steps")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -307,106 +336,132 @@ def main():
     dev_index = int(os.environ.get("CALM_LOCAL_DEVICE", local_rank))   # rehearsal: ranks may share a GPU
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    wl = WORKLOADS[args.workload]
-    batch = args.batch or wl["batch"]
-    S, classes = wl["kw"]["seq_length"], wl["kw"]["out_features"]
 
-    # under --autocast the region selects the bf16 pipeline itself; a global 'fp8' adds the fp8 Linear products to it
-    calm.backend.set_matmul_precision(("fp8" if args.precision == "fp8" else "fp32") if args.autocast else args.precision)
-    model = build_model(calm, wl["kw"], device).train()
-    trainer.sync_module_states(model)
-    x, y = synthetic_batch(batch, S, classes, seed=rank, device=device)     # resident in HBM before timing
-    if args.graph:
-        if world > 1:
-            raise SystemExit("--graph is single-GPU only")
-        opt = trainer.make_optimizer(model, capturable=True)
-        step = trainer.GraphedTrainStep(model, opt, x, y)
-        args.prof_steps = 0                                # events cannot be recorded inside a replayed graph
-    else:
-        opt = trainer.make_optimizer(model) if args.torch_optim else trainer.FusedClipAdamW(model)
-        reducer = trainer.BucketedGradReducer(model) if world > 1 else None
-        if args.autocast:
-            if args.precision != "fp8":
-                args.precision = "bf16"                     # what the autocast region selects; labels the JSON line
-            step = trainer.TrainStep(model, opt, reducer, scaler=torch.amp.GradScaler("cuda"),
-                                     autocast_dtype=torch.bfloat16)
+    def measure(workload, precision, autocast, steps, warmup, prof_steps, gemm_report=""):
+        """Build the workload's model, time `steps` training steps after `warmup`, then profile `prof_steps` more."""
+        wl = WORKLOADS[workload]
+        batch = (args.batch if workload == args.workload else 0) or wl["batch"]
+        S, classes = wl["kw"]["seq_length"], wl["kw"]["out_features"]
+        # under autocast the region selects the bf16 pipeline itself; a global 'fp8' adds the fp8 Linear products to it
+        calm.backend.set_matmul_precision(("fp8" if precision == "fp8" else "fp32") if autocast else precision)
+        model = build_model(calm, wl["kw"], device).train()
+        trainer.sync_module_states(model)
+        x, y = synthetic_batch(batch, S, classes, seed=rank, device=device)     # resident in HBM before timing
+        if args.graph:
+            if world > 1:
+                raise SystemExit("--graph is single-GPU only")
+            opt = trainer.make_optimizer(model, capturable=True)
+            step = trainer.GraphedTrainStep(model, opt, x, y)
+            prof_steps = 0                                 # events cannot be recorded inside a replayed graph
         else:
-            step = trainer.TrainStep(model, opt, reducer)
+            opt = trainer.make_optimizer(model) if args.torch_optim else trainer.FusedClipAdamW(model)
+            reducer = trainer.BucketedGradReducer(model) if world > 1 else None
+            if autocast:
+                if precision != "fp8":
+                    precision = "bf16"                      # what the autocast region selects; labels the JSON line
+                step = trainer.TrainStep(model, opt, reducer, scaler=torch.amp.GradScaler("cuda"),
+                                         autocast_dtype=torch.bfloat16)
+            else:
+                step = trainer.TrainStep(model, opt, reducer)
 
-    def sync():
+        def sync():
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        for _ in range(warmup):
+            step(x, y)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss, _ = step(x, y)
+        sync()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        res = {"workload": workload, "precision": precision, "batch": batch, "S": S, "wl": wl,
+               "ms_per_step": 1e3 * dt / steps, "value": world * batch * steps / dt, "loss": float(loss),
+               "roofline": None, "attention": None}
+
+        # dominant-kernel roofline: HIP events around every calm_gemm launch of prof_steps extra steps
+        if prof_steps > 0:
+            # every rank runs the profiled steps (they contain the gradient all-reduce); only rank 0 records
+            prof = GemmProfiler(calm.backend.get_backend()) if rank == 0 else None
+            aprof = AttentionProfiler(calm.backend.get_backend()) if rank == 0 else None
+            if prof is not None:
+                prof.__enter__()
+                aprof.__enter__()
+            for _ in range(prof_steps):
+                step(x, y)
+            if prof is not None:
+                aprof.__exit__()
+                prof.__exit__()
+                flops, ms, n = prof.summary()
+                if gemm_report:
+                    prof.report(gemm_report, prof_steps)
+                achieved = flops / (ms * 1e-3) / 1e12
+                _, peak, klabel = PRECISION_INFO[precision]
+                roofline = {"bound": "mfma", "kernel": klabel,
+                            "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
+                            "frac": round(achieved / peak, 4),
+                            "traffic": None,
+                            "launches_per_step": n // prof_steps, "avg_launch_us": round(1e3 * ms / n, 2),
+                            "gemm_ms_per_step": round(ms / prof_steps, 2),
+                            "algorithmic_gflop_per_step": round(flops / prof_steps / 1e9, 1)}
+                # HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate passes) from the committed summary
+                detail = pmc_traffic(GEMM_PMC_PREFIX["fp32" if precision == "fp32" else "bf16"])
+                if detail is not None:
+                    roofline["traffic"] = detail["hbm_bytes_per_launch"]
+                    roofline["traffic_detail"] = detail
+                res["roofline"] = roofline
+                # the axial-attention kernel (the other half of BASELINE.json's metric): live launch times of the fused
+                # forward + the MFMA utilisation / HBM rate of the committed PMC summary (refused when stale)
+                a = aprof.summary()
+                if a is not None:
+                    name, aS, aH, ahd = a["largest"]
+                    kname = "attn16_fwd_kernel" if name == "attn16_fwd" else "attn_fwd_kernel"
+                    rows, source, stale = pmc_rows(kname)
+                    best = max(rows, key=lambda r: float(r["gui_active_sum"])) if rows and not stale else None
+                    res["attention"] = {
+                        "kernel": f"{kname} (fused latent-mask attention forward, "
+                                  f"{'v_mfma_f32_16x16x32_bf16' if name == 'attn16_fwd' else 'v_mfma_f32_16x16x4_f32'})",
+                        "bound": "mfma", "launches_per_step": a["n"] // prof_steps,
+                        "ms_per_step": round(a["ms"] / prof_steps, 3),
+                        "achieved": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2), "peak": round(peak, 1),
+                        "unit": "TFLOP/s", "frac": round(a["flops"] / (a["ms"] * 1e-3) / 1e12 / peak, 4),
+                        "largest_shape": {"S": aS, "H": aH, "hd": ahd, "avg_launch_us": round(a["largest_us"], 1),
+                                          "tflops": round(a["largest_tflops"], 2)},
+                        "mfma_util_pmc": round(float(best["mfma_util"]), 4) if best else None,
+                        "hbm_GBps_pmc": round(float(best["hbm_GBps"]), 1) if best else None,
+                        "pmc_kernel": best["kernel"] if best else None, "pmc_source": source, "pmc_stale": stale}
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        res["hbm_peak_gib"] = round(torch.cuda.max_memory_allocated(device) / 2**30, 1)
+        if isinstance(opt, trainer.FusedClipAdamW):
+            opt.close()
+        del step, opt, model
+        torch.cuda.empty_cache()
+        return res
 
-    for _ in range(args.warmup):
-        step(x, y)
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, _ = step(x, y)
-    sync()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = 1e3 * dt / args.steps
-    value = world * batch * args.steps / dt
-
-    # dominant-kernel roofline: HIP events around every calm_gemm launch of prof_steps extra steps
-    roofline = None
-    if args.prof_steps > 0:
-        # every rank runs the profiled steps (they contain the gradient all-reduce); only rank 0 records
-        prof = GemmProfiler(calm.backend.get_backend()) if rank == 0 else None
-        aprof = AttentionProfiler(calm.backend.get_backend()) if rank == 0 else None
-        if prof is not None:
-            prof.__enter__()
-            aprof.__enter__()
-        for _ in range(args.prof_steps):
-            step(x, y)
-        if prof is not None:
-            aprof.__exit__()
-            prof.__exit__()
-            flops, ms, n = prof.summary()
-            if args.gemm_report:
-                prof.report(args.gemm_report, args.prof_steps)
-            achieved = flops / (ms * 1e-3) / 1e12
-            _, peak, klabel = PRECISION_INFO[args.precision]
-            roofline = {"bound": "mfma", "kernel": klabel,
-                        "achieved": round(achieved, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                        "frac": round(achieved / peak, 4),
-                        "traffic": None,
-                        "launches_per_step": n // args.prof_steps, "avg_launch_us": round(1e3 * ms / n, 2),
-                        "gemm_ms_per_step": round(ms / args.prof_steps, 2),
-                        "algorithmic_gflop_per_step": round(flops / args.prof_steps / 1e9, 1)}
-            # HBM bytes per launch (PMC: 2 x FETCH_SIZE + WRITE_SIZE, separate passes) from the committed summary
-            detail = pmc_traffic(GEMM_PMC_PREFIX["fp32" if args.precision == "fp32" else "bf16"])
-            if detail is not None:
-                roofline["traffic"] = detail["hbm_bytes_per_launch"]
-                roofline["traffic_detail"] = detail
-            # the axial-attention kernel (the other half of BASELINE.json's metric): live launch times of the fused
-            # forward + the MFMA utilisation / HBM rate of the committed PMC summary (refused when stale)
-            a = aprof.summary()
-            if a is not None:
-                name, aS, aH, ahd = a["largest"]
-                kname = "attn16_fwd_kernel" if name == "attn16_fwd" else "attn_fwd_kernel"
-                rows, source, stale = pmc_rows(kname)
-                best = max(rows, key=lambda r: float(r["gui_active_sum"])) if rows and not stale else None
-                attention = {"kernel": f"{kname} (fused latent-mask attention forward, "
-                                       f"{'v_mfma_f32_16x16x32_bf16' if name == 'attn16_fwd' else 'v_mfma_f32_16x16x4_f32'})",
-                             "bound": "mfma", "launches_per_step": a["n"] // args.prof_steps,
-                             "ms_per_step": round(a["ms"] / args.prof_steps, 3),
-                             "achieved": round(a["flops"] / (a["ms"] * 1e-3) / 1e12, 2), "peak": round(peak, 1),
-                             "unit": "TFLOP/s", "frac": round(a["flops"] / (a["ms"] * 1e-3) / 1e12 / peak, 4),
-                             "largest_shape": {"S": aS, "H": aH, "hd": ahd, "avg_launch_us": round(a["largest_us"], 1),
-                                               "tflops": round(a["largest_tflops"], 2)},
-                             "mfma_util_pmc": round(float(best["mfma_util"]), 4) if best else None,
-                             "hbm_GBps_pmc": round(float(best["hbm_GBps"]), 1) if best else None,
-                             "pmc_kernel": best["kernel"] if best else None, "pmc_source": source, "pmc_stale": stale}
-            else:
-                attention = None
-    if world > 1:
-        dist.barrier()
+    main_res = measure(args.workload, args.precision, args.autocast, args.steps, args.warmup, args.prof_steps, args.gemm_report)
+    args.precision = main_res["precision"]
+    wl, batch, S = main_res["wl"], main_res["batch"], main_res["S"]
+    value, ms_per_step, loss = main_res["value"], main_res["ms_per_step"], main_res["loss"]
+    roofline, attention = main_res["roofline"], main_res["attention"]
+    # the reference's own configuration (BASELINE configs[2]: Base-224 under autocast(bfloat16) + GradScaler, cls:84-95) in
+    # the same run, so that the driver's record carries it beside the fp32 headline (VERDICT r2 #3): >= 10 timed steps
+    secondary = None
+    if world == 1 and not args.no_secondary and args.workload == "small224" and not args.autocast and not args.graph:
+        torch.cuda.reset_peak_memory_stats(device)
+        r2 = measure("base224", "bf16", True, 10, 3, 1)
+        secondary = {"workload": f"CALM-ViT base224 cls (the reference's model), 224x224x3 synthetic, bs={r2['batch']}/GPU, "
+                                 "torch.autocast(bfloat16) + GradScaler, fwd+loss+bwd+clip+AdamW",
+                     "metric": "training images/sec (224^2, bs=256/GPU)", "value": round(r2["value"], 2), "unit": "images/sec",
+                     "steps": 10, "warmup": 3, "ms_per_step": round(r2["ms_per_step"], 3), "dtype": PRECISION_INFO["bf16"][0],
+                     "model_tflops": round(r2["value"] * r2["wl"]["gflop_img"] / 1e3, 2), "hbm_peak_gib": r2["hbm_peak_gib"],
+                     "roofline": r2["roofline"], "attention": r2["attention"]}
 
     if rank == 0:
         out = {
@@ -420,14 +475,16 @@ def main():
                        "global_batch": world * batch,
                        "parallelism": f"dp{world}", "world": dist.get_world_size() if dist.is_initialized() else 1,
                        "backend": dist.get_backend() if dist.is_initialized() else "none (single process)",
-                       "loss": float(loss), "hipgraph": bool(args.graph),
+                       "loss": loss, "hipgraph": bool(args.graph),
                        "optimizer": "torch clip_grad_norm_ + AdamW" if (args.torch_optim or args.graph)
                        else "calm_optim_step (norm + clip + AdamW + spectral-norm grad correction, 3 launches)"},
             "model_tflops": round(value * wl["gflop_img"] / 1e3, 2),
-            "hbm_peak_gib": round(torch.cuda.max_memory_allocated(device) / 2**30, 1),
+            "hbm_peak_gib": main_res["hbm_peak_gib"],
             "roofline": roofline,
             "attention": attention if roofline is not None else None,
         }
+        if secondary is not None:
+            out["secondary"] = secondary
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)

@@ -14,7 +14,7 @@ ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 F32 = 0
 ST_F32, ST_BF16, ST_FP8_E4M3, ST_FP8_E5M2 = 0, 1, 2, 3   # storage type of a tensor in HBM (CALM_ST_*)
 E_INVAL, E_LAYOUT, E_UNSUPP = -1, -2, -3      # CALM_E_*
-ABI_VERSION = 4          # CALM_ABI_VERSION of include/calm_vit.h
+ABI_VERSION = 5          # CALM_ABI_VERSION of include/calm_vit.h
 
 _p = C.c_void_p
 _i32 = C.c_int32
@@ -106,6 +106,7 @@ SIGNATURES = {
     "calm_optim_chunk_elems": (_i32, []),
     "calm_optim_step": (_i32, [_p, _i32, _p, _i32, _p, C.POINTER(OptimHparams), _p, _p, _p, _p]),
     "calm_collate_mix": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p]),
+    "calm_collate_crop_mix": (_i32, [_p, _i32, _i32, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p]),
     "calm_image_to_rows": (_i32, [_p, _p, _i32, _i32, _p]),
     "calm_rows_to_image": (_i32, [_p, _p, _i32, _i32, _p]),
     "calm_grid_transpose": (_i32, [_p, _p, _i32, _i32, _p]),

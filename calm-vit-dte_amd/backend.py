@@ -278,6 +278,25 @@ class HipBackend:
         _lib.check(self.lib.calm_collate_mix(img_u8.data_ptr(), fp, _ptr(out), B, H, W, mode, float(lam), cbox, cm, cs,
                                              _stream()), "calm_collate_mix")
 
+    def collate_crop_mix(self, img_u8, crop_yx, flip, out, mode, lam, box, mean, std, tokens=False):
+        """img_u8 [B,3,Hs,Ws] uint8; crop_yx [B,2] int32 on the device (or None); out [B,3,H,W] or, tokens=True,
+        [B,H,3W] fp32 (the row tokens of the first Block)."""
+        if not img_u8.is_cuda or img_u8.dtype != torch.uint8 or not img_u8.is_contiguous():
+            raise TypeError("collate_crop_mix expects a contiguous uint8 CUDA image batch")
+        B, _, Hs, Ws = img_u8.shape
+        if tokens:
+            H, W = out.shape[1], out.shape[2] // 3
+        else:
+            H, W = out.shape[2], out.shape[3]
+        if crop_yx is not None and (crop_yx.dtype != torch.int32 or not crop_yx.is_cuda or not crop_yx.is_contiguous()):
+            raise TypeError("collate_crop_mix: crop_yx must be a contiguous int32 CUDA tensor [B,2]")
+        cbox = (C.c_int32 * 4)(*box) if box is not None else None
+        cm, cs = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+        _lib.check(self.lib.calm_collate_crop_mix(img_u8.data_ptr(), Hs, Ws, crop_yx.data_ptr() if crop_yx is not None else None,
+                                                  flip.data_ptr() if flip is not None else None, _ptr(out), B, H, W,
+                                                  int(tokens), mode, float(lam), cbox, cm, cs, _stream()),
+                   "calm_collate_crop_mix")
+
     # ---- optimizer-side step ------------------------------------------------------------
     def optim_plan(self, records):
         """records: one dict per parameter — param, exp_avg, exp_avg_sq, sn (None or (u, v, sigma, rows, cols))."""

@@ -90,6 +90,11 @@ static int pipe_run(const calm_gemm_args* a, GemmP& p, bool akc, bool bkc, hipSt
     const bool k_split = group_split || a->split_k > 1 ||
                          (a->split_k == 0 && batch == 1 && trivial_epi && tiles_min < 128 && kpb >= 32);
     if (k_split && !group_split && batch != 1) return PIPE_DECLINED;
+    // where the 256-thread kernels measured faster inside the training step (Base-224, same box): narrow k-split outputs,
+    // small grouped weight gradients, reductions of two or three k-tiles
+    if (k_split && (a->M < 200 || a->N < 200)) return PIPE_DECLINED;
+    if (group_split && (int64_t)a->M * a->N < 100000) return PIPE_DECLINED;
+    if (!k_split && a->K < 160) return PIPE_DECLINED;
     if (k_split && (!trivial_epi || a->c_type != CALM_ST_F32)) return PIPE_DECLINED;
 
     int best_mt = 0, best_nt = 0, best_split = 1;

@@ -155,26 +155,42 @@ __global__ __launch_bounds__(NT) void dwconv_bwd_kernel(const float* __restrict_
 // flip + the batch-level CutMix / MixUp of distributed_trainer_cls.py:58-61,128-139 in one pass over uint8 images.
 //   out[b,c,y,x] = w * n(img[b]) + (1 - w) * n(img[(b - 1) mod B])       n(v) = (v/255 - mean[c]) / std[c]
 //   MixUp : w = lam everywhere;  CutMix: w = 0 inside the box [y1,y2) x [x1,x2), 1 outside (partner = batch rolled by 1)
-__global__ __launch_bounds__(NT) void collate_mix_kernel(const unsigned char* __restrict__ img,
+// TOKENS: the output is the row-token tensor [B, H, 3W] the first Block consumes (rows[b,i,3j+c] = img[b,c,i,j],
+// Vi_Tools_CNN_less_V2.py:389-391) instead of the [B,3,H,W] image; crop: per-sample top-left corner of the H x W window
+// inside the Hs x Ws source (RandomCrop, distributed_trainer_cls.py:130), NULL = (0, 0).
+template <bool TOKENS>
+__global__ __launch_bounds__(NT) void collate_mix_kernel(const unsigned char* __restrict__ img, int Hs, int Ws,
+                                                         const int* __restrict__ crop,
                                                          const unsigned char* __restrict__ flip, float* __restrict__ out,
                                                          int B, int H, int W, int mode, float lam, int y1, int y2,
                                                          int x1, int x2, float m0, float m1, float m2, float i0, float i1,
                                                          float i2) {
     const long total = (long)B * 3 * H * W;
+    const long splane = (long)Hs * Ws;
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const int x = (int)(i % W);
-        const int y = (int)((i / W) % H);
-        const int c = (int)((i / ((long)W * H)) % 3);
-        const int b = (int)(i / ((long)W * H * 3));
+        int x, y, c, b;
+        if (TOKENS) {                       // i = (b, y, 3 x + c)
+            c = (int)(i % 3);
+            x = (int)((i / 3) % W);
+            y = (int)((i / (3L * W)) % H);
+            b = (int)(i / (3L * W * H));
+        } else {                            // i = (b, c, y, x)
+            x = (int)(i % W);
+            y = (int)((i / W) % H);
+            c = (int)((i / ((long)W * H)) % 3);
+            b = (int)(i / ((long)W * H * 3));
+        }
         const int pb = b == 0 ? B - 1 : b - 1;
         const float mean = c == 0 ? m0 : c == 1 ? m1 : m2, inv = c == 0 ? i0 : c == 1 ? i1 : i2;
-        const long plane = ((long)c * H + y) * W;
         const int xs = flip && flip[b] ? W - 1 - x : x;
         const int xp = flip && flip[pb] ? W - 1 - x : x;
-        const float own = ((float)img[(long)b * 3 * H * W + plane + xs] * (1.0f / 255.0f) - mean) * inv;
+        const int oy = crop ? crop[2 * b] : 0, ox = crop ? crop[2 * b + 1] : 0;
+        const float own = ((float)img[((long)b * 3 + c) * splane + (long)(oy + y) * Ws + ox + xs] * (1.0f / 255.0f) - mean) * inv;
         float v = own;
         if (mode != 0) {
-            const float oth = ((float)img[(long)pb * 3 * H * W + plane + xp] * (1.0f / 255.0f) - mean) * inv;
+            const int py = crop ? crop[2 * pb] : 0, px = crop ? crop[2 * pb + 1] : 0;
+            const float oth =
+                ((float)img[((long)pb * 3 + c) * splane + (long)(py + y) * Ws + px + xp] * (1.0f / 255.0f) - mean) * inv;
             if (mode == 1) v = own * lam + oth * (1.0f - lam);                 // MixUp: x.roll(1,0)*(1-lam) + x*lam
             else if (y >= y1 && y < y2 && x >= x1 && x < x2) v = oth;          // CutMix box
         }
@@ -186,16 +202,27 @@ __global__ __launch_bounds__(NT) void collate_mix_kernel(const unsigned char* __
 
 extern "C" {
 
-int calm_collate_mix(const uint8_t* img_u8, const uint8_t* flip, float* out, int32_t B, int32_t H, int32_t W,
-                     int32_t mode, float lam, const int32_t* box, const float* mean, const float* std, void* stream) {
-    if (!img_u8 || !out || !mean || !std || B <= 0 || H <= 0 || W <= 0 || mode < 0 || mode > 2) return CALM_E_INVAL;
+int calm_collate_crop_mix(const uint8_t* img_u8, int32_t Hs, int32_t Ws, const int32_t* crop_yx, const uint8_t* flip,
+                          float* out, int32_t B, int32_t H, int32_t W, int32_t out_tokens, int32_t mode, float lam,
+                          const int32_t* box, const float* mean, const float* std, void* stream) {
+    if (!img_u8 || !out || !mean || !std || B <= 0 || H <= 0 || W <= 0 || Hs < H || Ws < W || mode < 0 || mode > 2) return CALM_E_INVAL;
     if (mode == 2 && !box) return CALM_E_INVAL;
+    if (!crop_yx && (Hs != H || Ws != W)) return CALM_E_INVAL;
     int g = grid_for((int64_t)B * 3 * H * W, NT * 4);
-    hipLaunchKernelGGL(collate_mix_kernel, dim3(g), dim3(NT), 0, as_stream(stream), img_u8, flip, out, B, H, W, mode, lam,
-                       box ? box[0] : 0, box ? box[1] : 0, box ? box[2] : 0, box ? box[3] : 0, mean[0], mean[1], mean[2],
-                       1.0f / std[0], 1.0f / std[1], 1.0f / std[2]);
+    const int y1 = box ? box[0] : 0, y2 = box ? box[1] : 0, x1 = box ? box[2] : 0, x2 = box ? box[3] : 0;
+    if (out_tokens)
+        hipLaunchKernelGGL(collate_mix_kernel<true>, dim3(g), dim3(NT), 0, as_stream(stream), img_u8, Hs, Ws, crop_yx, flip, out, B, H,
+                           W, mode, lam, y1, y2, x1, x2, mean[0], mean[1], mean[2], 1.0f / std[0], 1.0f / std[1], 1.0f / std[2]);
+    else
+        hipLaunchKernelGGL(collate_mix_kernel<false>, dim3(g), dim3(NT), 0, as_stream(stream), img_u8, Hs, Ws, crop_yx, flip, out, B, H,
+                           W, mode, lam, y1, y2, x1, x2, mean[0], mean[1], mean[2], 1.0f / std[0], 1.0f / std[1], 1.0f / std[2]);
     CALM_LAUNCH_CHECK();
     return 0;
+}
+
+int calm_collate_mix(const uint8_t* img_u8, const uint8_t* flip, float* out, int32_t B, int32_t H, int32_t W,
+                     int32_t mode, float lam, const int32_t* box, const float* mean, const float* std, void* stream) {
+    return calm_collate_crop_mix(img_u8, H, W, nullptr, flip, out, B, H, W, 0, mode, lam, box, mean, std, stream);
 }
 
 int calm_image_to_rows(const float* img, float* rows, int32_t B, int32_t S, void* stream) {

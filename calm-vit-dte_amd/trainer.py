@@ -103,13 +103,18 @@ class BucketedGradReducer:
     mean inside the collective; gloo on CPU in tests: SUM then a scale).  `finish()` (call after backward) makes the
     compute stream wait for the collectives and re-points every `p.grad` at its slice of the reduced bucket — no copy
     back: the optimizer-side step reads the buckets in place, and since those addresses never change its gradient
-    pointer table is uploaded once."""
+    pointer table is uploaded once.  (The gradients are PACKED into the bucket by one `_foreach_copy_` per bucket: the
+    optimizer-side step releases `.grad`, so autograd's AccumulateGrad adopts the freshly produced gradient buffers —
+    keeping `.grad` pointed at the bucket views across steps would instead make autograd add into them, one extra
+    read-modify-write launch per parameter.)"""
 
-    def __init__(self, model, bucket_mb=64, process_group=None, tail_mb=8):
+    def __init__(self, model, bucket_mb=64, process_group=None, tail_mb=8, force=False):
+        """force: run the buckets and collectives in a world of one as well (a single-GPU RCCL rehearsal of exactly the
+        code path the 8-GPU job takes; needs an initialised process group)."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in model.parameters() if p.requires_grad]
-        self.enabled = self.world > 1
+        self.enabled = self.world > 1 or (force and dist.is_initialized())
         self.buckets = []
         self._works = []
         if not self.enabled:
@@ -288,23 +293,33 @@ class DeviceCollate:
         lam = float(rng.beta(alpha, alpha))
         box = None
         if mode == 2:
-            rx, ry = int(rng.integers(0, W)), int(rng.integers(0, H))
-            r = 0.5 * (1.0 - lam) ** 0.5
-            hw, hh = int(r * W), int(r * H)
-            x1, y1, x2, y2 = max(rx - hw, 0), max(ry - hh, 0), min(rx + hw, W), min(ry + hh, H)
-            box = (y1, y2, x1, x2)
-            lam = 1.0 - (x2 - x1) * (y2 - y1) / float(W * H)
+            box, lam = SoftMixCollate.cutmix_box(lam, int(rng.integers(0, W)), int(rng.integers(0, H)), H, W)
         flips = torch.from_numpy((rng.random(B) < self.flip_p).astype("uint8"))
         return mode, lam, box, flips
 
-    def __call__(self, img_u8, labels, decisions=None):
+    def __call__(self, img_u8, labels, decisions=None, crop=None, tokens=False):
+        """crop=(H, W): RandomCrop of every sample to H x W inside the (resized) source, corners drawn uniformly as
+        torchvision's RandomCrop.get_params does (cls:130); tokens=True: the batch comes out as the row tokens
+        [B, H, 3W] of the first Block (Vi_Tools_CNN_less_V2.py:389-391) — feed it to `model.autoencoder` / a ViT whose
+        first Block skips the tokenisation — instead of the image [B,3,H,W]."""
         from .backend import get_backend
-        B, _, H, W = img_u8.shape
+        B, _, Hs, Ws = img_u8.shape
+        H, W = crop if crop is not None else (Hs, Ws)
         mode, lam, box, flips = decisions if decisions is not None else self.draw(B, H, W)
-        out = torch.empty(img_u8.shape, dtype=torch.float32, device=img_u8.device)
-        get_backend().collate_mix(img_u8, flips.to(img_u8.device), out, mode, lam, box, self.MEAN, self.STD)
+        corners = None
+        if crop is not None:
+            import numpy as np
+            corners = torch.from_numpy(np.stack([self.rng.integers(0, Hs - H + 1, B), self.rng.integers(0, Ws - W + 1, B)],
+                                                axis=1).astype("int32")).to(img_u8.device)
+        out = torch.empty((B, H, 3 * W) if tokens else (B, 3, H, W), dtype=torch.float32, device=img_u8.device)
+        if crop is None and not tokens:
+            get_backend().collate_mix(img_u8, flips.to(img_u8.device), out, mode, lam, box, self.MEAN, self.STD)
+        else:
+            get_backend().collate_crop_mix(img_u8, corners, flips.to(img_u8.device), out, mode, lam, box, self.MEAN, self.STD,
+                                           tokens=tokens)
         onehot = torch.nn.functional.one_hot(labels, self.num_classes).to(torch.float32)
         y = onehot * lam + onehot.roll(1, 0) * (1.0 - lam)
+        self.last_corners = corners
         return out, y
 
 
@@ -355,14 +370,16 @@ def make_optimizer(model, lr=3.1e-3, weight_decay=0.02, betas=(0.9, 0.98), captu
                              capturable=capturable and fused)
 
 
-def _clear_deferred(refs, attr):
+def _clear_deferred(refs, attr, token):
+    """Remove the deferral mark from the parameters that still carry THIS optimizer's token: a mark re-set by a newer
+    optimizer on the same model is not the dropped one's to clear (its finalizer may run long after the new one exists)."""
     for r in refs:
         p = r()
-        if p is not None and hasattr(p, attr):
+        if p is not None and getattr(p, attr, None) == token:
             delattr(p, attr)
 
 
-class FusedClipAdamW:
+class FusedClipAdamW(torch.optim.Optimizer):
     """unscale + inf/NaN check + clip_grad_norm_(max_norm) + AdamW + zero_grad of distributed_trainer_cls.py:88-96 as
     THREE kernel launches over all parameters (calm_optim_step), with the spectral-norm weight-gradient correction
     folded in: while an instance is live, the backward of every spectral-normed layer that is not combined with a
@@ -370,15 +387,20 @@ class FusedClipAdamW:
     less) and this step applies dW_orig = (G - <G, W/sigma> u v^T)/sigma on the fly — so between backward and step()
     those `.grad`s are NOT the reference's gradients; mean all-reduce commutes with the correction (it is linear and
     u, v, sigma, W are replicated), so the BucketedGradReducer / DDP run unchanged in between.  close() restores the
-    in-backward correction.  Same update rule, hyper-parameters and state names as torch.optim.AdamW."""
+    in-backward correction.  Same update rule, hyper-parameters and state names as torch.optim.AdamW.
+
+    It IS a torch.optim.Optimizer (one param group): `CosineAnnealingLR(optimizer, T_max=epochs, eta_min=1e-6)` of the
+    reference's train() (cls:52,108-109) wraps it, and the learning rate a step uses is `param_groups[0]["lr"]`."""
 
     def __init__(self, model, lr=3.1e-3, weight_decay=0.02, betas=(0.9, 0.98), eps=1e-8, max_norm=1.0, defer_sn=True):
         from . import ops
         from .backend import get_backend
         from .spectral_norm import SpectralWeight
         self.be = get_backend()
-        self.lr, self.weight_decay, self.betas, self.eps, self.max_norm = lr, weight_decay, betas, eps, max_norm
-        self.params = [p for p in model.parameters() if p.requires_grad]
+        self.max_norm = max_norm
+        params = [p for p in model.parameters() if p.requires_grad]
+        super().__init__(params, dict(lr=lr, weight_decay=weight_decay, betas=tuple(betas), eps=eps))
+        self.params = params
         self.exp_avg = [torch.zeros_like(p) for p in self.params]
         self.exp_avg_sq = [torch.zeros_like(p) for p in self.params]
         sn = {}
@@ -398,11 +420,17 @@ class FusedClipAdamW:
         self._plan = self.be.optim_plan(records)
         # the deferral is a mark on the PARAMETER OBJECT (ops reads it in forward), not a set of raw addresses: it
         # survives a re-materialised buffer and cannot be inherited by an unrelated tensor at a recycled address
+        # The mark carries its owner: a second optimizer built over the same model takes the marks over, and the first
+        # one's finalizer (or close()) then leaves them alone — clearing them would make backward correct the gradient
+        # AND this step correct it again.
+        self._token = id(self)
+        self._defer_attr = ops.DEFER_ATTR
         for p in self._deferred:
-            setattr(p, ops.DEFER_ATTR, True)
+            setattr(p, ops.DEFER_ATTR, self._token)
         # an optimizer that is dropped without close() must not leave its layers deferred (their backward would hand
         # out un-corrected gradients with nobody left to correct them)
-        self._finalizer = weakref.finalize(self, _clear_deferred, [weakref.ref(p) for p in self._deferred], ops.DEFER_ATTR)
+        self._finalizer = weakref.finalize(self, _clear_deferred, [weakref.ref(p) for p in self._deferred], ops.DEFER_ATTR,
+                                           self._token)
         self.stats = torch.zeros(2, dtype=torch.float32, device=self.params[0].device)   # [grad norm, found_inf]
 
     @property
@@ -410,6 +438,12 @@ class FusedClipAdamW:
         """Completed (un-skipped) optimizer steps: the counter lives on the device and does not advance when an
         inf/NaN gradient skips the update — torch.optim.AdamW under a GradScaler.  Reading it synchronises."""
         return int(self._plan.step_dev.item())
+
+    # the hyper-parameters live in the (single) param group, where LR schedulers read and write them
+    lr = property(lambda self: self.param_groups[0]["lr"], lambda self, v: self.param_groups[0].__setitem__("lr", v))
+    weight_decay = property(lambda self: self.param_groups[0]["weight_decay"])
+    betas = property(lambda self: self.param_groups[0]["betas"])
+    eps = property(lambda self: self.param_groups[0]["eps"])
 
     def close(self):
         self._finalizer()
@@ -429,10 +463,16 @@ class FusedClipAdamW:
                                "after the model is on its final device")
 
     @torch.no_grad()
-    def step(self, grad_scale=None):
+    def step(self, closure=None, grad_scale=None):
         """One optimizer-side step on the current `.grad`s; grads are released (set to None) afterwards.
         grad_scale: device scalar the loss was multiplied by (GradScaler), or None.  Returns the stats tensor."""
+        if closure is not None:
+            raise NotImplementedError("FusedClipAdamW.step takes no closure")
         self._check_plan()
+        for p in self._deferred:
+            if getattr(p, self._defer_attr, None) != self._token:
+                raise RuntimeError("FusedClipAdamW: another optimizer took over (or cleared) the deferred spectral-norm "
+                                   "correction of this model; only the newest optimizer of a model may step")
         grads = []
         for p in self.params:
             g = p.grad
@@ -441,7 +481,7 @@ class FusedClipAdamW:
             elif not g.is_contiguous():
                 g = p.grad = g.contiguous()
             grads.append(g)
-        hp = (self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_norm or 0.0, 0)
+        hp = (float(self.lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_norm or 0.0, 0)
         self.be.optim_step(self._plan, grads, hp, grad_scale, self.stats)
         for p in self.params:
             p.grad = None
@@ -457,6 +497,8 @@ class FusedClipAdamW:
                                 max_norm=self.max_norm)}
 
     def load_state_dict(self, sd):
+        if "hparams" in sd:
+            self.lr = sd["hparams"]["lr"]
         self._plan.step_dev.fill_(int(sd["step"]))
         for dst, src in zip(self.exp_avg, sd["exp_avg"]):
             dst.copy_(src)
@@ -490,3 +532,133 @@ class GraphedTrainStep:
         self.y.copy_(y_soft, non_blocking=True)
         self.graph.replay()
         return self.loss, self.y_hat
+
+
+class SoftMixCollate:
+    """collate_fn of the reference's DataLoader (distributed_trainer_cls.py:58-62): default_collate, then
+    RandomChoice([CutMix(num_classes, alpha=1.0), MixUp(num_classes, alpha=0.8)]) on the batch — torchvision.transforms.v2
+    semantics restated (torchvision is not installed here; tests/golden/mix_vectors.json pins them): the partner of
+    sample i is sample i-1 (`roll(1, 0)`), lam ~ Beta(alpha, alpha);
+      MixUp : x = lam x + (1 - lam) x_rolled,                      y = lam onehot + (1 - lam) onehot_rolled
+      CutMix: a box of area ratio (1 - lam) centred at a uniform point, clipped to the image, is pasted from the
+              partner; lam is then corrected to 1 - box_area / image_area.
+    Host side, float images [B,3,H,W]; `DeviceCollate` is the uint8-on-device form of the same decisions."""
+
+    def __init__(self, num_classes=1000, cutmix_alpha=1.0, mixup_alpha=0.8, seed=None):
+        import numpy as np
+        self.num_classes, self.cutmix_alpha, self.mixup_alpha = num_classes, cutmix_alpha, mixup_alpha
+        self.rng = np.random.default_rng(seed)
+
+    @staticmethod
+    def cutmix_box(lam, cx, cy, H, W):
+        """torchvision v2 CutMix._get_params: r = 0.5 sqrt(1 - lam); box = centre -+ (r W, r H) truncated to ints and
+        clipped; returns (y1, y2, x1, x2) and the corrected lam."""
+        r = 0.5 * (1.0 - lam) ** 0.5
+        rw, rh = int(r * W), int(r * H)
+        x1, y1, x2, y2 = max(cx - rw, 0), max(cy - rh, 0), min(cx + rw, W), min(cy + rh, H)
+        return (y1, y2, x1, x2), 1.0 - (x2 - x1) * (y2 - y1) / float(W * H)
+
+    def mix(self, x, labels, mode, lam, box=None):
+        onehot = torch.nn.functional.one_hot(labels, self.num_classes).to(torch.float32)
+        xr = x.roll(1, 0)
+        if mode == 1:
+            out = x * lam + xr * (1.0 - lam)
+        else:
+            y1, y2, x1, x2 = box
+            out = x.clone()
+            out[..., y1:y2, x1:x2] = xr[..., y1:y2, x1:x2]
+        return out, onehot * lam + onehot.roll(1, 0) * (1.0 - lam)
+
+    def __call__(self, batch):
+        x = torch.stack([b[0] for b in batch])
+        labels = torch.as_tensor([int(b[1]) for b in batch])
+        H, W = x.shape[-2:]
+        mode = 2 if self.rng.random() < 0.5 else 1
+        alpha = self.cutmix_alpha if mode == 2 else self.mixup_alpha
+        lam = float(self.rng.beta(alpha, alpha))
+        box = None
+        if mode == 2:
+            box, lam = self.cutmix_box(lam, int(self.rng.integers(0, W)), int(self.rng.integers(0, H)), H, W)
+        return self.mix(x, labels, mode, lam, box)
+
+
+def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, epochs=15, batch_size=128,
+          checkpoint_path=None, num_classes=1000, num_workers=0, collate_fn="mix", log_every=100, max_steps=None,
+          destroy_process_group=True):
+    """Per-rank training job: the reference's `train(initializer, optimizer, scheduler, use_gpu, dataset, epochs,
+    batch_size)` (distributed_trainer_cls.py:25-114) on torch.distributed + RCCL instead of Spark's TorchDistributor —
+    start one process per GPU with `python -m torch.distributed.run --nproc-per-node N ...` (RANK / LOCAL_RANK /
+    WORLD_SIZE from the environment, cls:48-50).
+
+      * init_process_group (nccl on GPUs, gloo on CPU)                                   cls:46
+      * CosineAnnealingLR(optimizer, T_max=epochs, eta_min=1e-6), stepped once per epoch  cls:52,108-109
+        (the reference builds it whatever `scheduler` it is handed; pass scheduler=False for a constant rate)
+      * model.to(device); parameters + buffers broadcast from rank 0; gradients mean-all-reduced in buckets on a side
+        stream (sync_module_states + BucketedGradReducer = what DDP(model) does)          cls:54-55
+      * DistributedSampler(dataset, shuffle=True, seed=2006), set_epoch(epoch)           cls:56-57,73
+      * DataLoader with the CutMix / MixUp soft-label collate                            cls:58-62
+      * per step: autocast(bf16) forward, CE, GradScaler, clip_grad_norm_(1.0), optimizer step, zero_grad   cls:79-96
+      * rank 0: loss / dominant-class accuracy print every 100 steps, state_dict checkpoint per epoch      cls:97-107
+      * returns the model on the CPU after destroy_process_group()                       cls:112-114
+
+    optimizer: a torch optimizer over `initializer.parameters()` (the reference hands in AdamW(lr=3.1e-3,
+    weight_decay=0.02, betas=(0.9, 0.98))), or the string "fused" for FusedClipAdamW with those hyper-parameters (built
+    here, after the model is on its device).  checkpoint_path: the reference writes /config/Codebase/models/model_cls.pth."""
+    from torch.utils.data import DataLoader, DistributedSampler
+    rank, local_rank, world = init_distributed(use_gpu)
+    device = torch.device(f"cuda:{local_rank}" if use_gpu else "cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    model = initializer.to(device)
+    if optimizer == "fused":
+        optimizer = FusedClipAdamW(model)
+    if scheduler is None or scheduler is True:
+        scheduler = torch.optim.lr_scheduler.CosineAnnealingLR(optimizer, T_max=epochs, eta_min=1e-6)      # cls:52
+    elif scheduler is False:
+        scheduler = None
+    sync_module_states(model)
+    reducer = BucketedGradReducer(model) if world > 1 else None
+    if world > 1:
+        sampler = DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True, seed=2006)       # cls:56
+    else:
+        sampler = DistributedSampler(dataset, num_replicas=1, rank=0, shuffle=True, seed=2006)
+    sampler.set_epoch(0)
+    if collate_fn == "mix":
+        collate_fn = SoftMixCollate(num_classes=num_classes, seed=2006 + rank)
+    loader = DataLoader(dataset, batch_size=batch_size, sampler=sampler, collate_fn=collate_fn, num_workers=num_workers,
+                        pin_memory=use_gpu, persistent_workers=num_workers > 0)
+    scaler = torch.amp.GradScaler("cuda", enabled=use_gpu)                                                 # cls:64
+    step = TrainStep(model, optimizer, reducer, max_norm=1.0, scaler=scaler if use_gpu else None,
+                     autocast_dtype=torch.bfloat16 if use_gpu else None)
+    model.train()
+    n_steps = 0
+    try:
+        for epoch in range(epochs):
+            sampler.set_epoch(epoch)
+            model.train()
+            epoch_loss = 0.0
+            for i, (x, y) in enumerate(loader):
+                x, y = x.to(device, non_blocking=True), y.to(device, non_blocking=True)
+                loss, y_hat = step(x, y)
+                epoch_loss += loss.item()                                                                  # cls:97
+                if rank == 0 and local_rank == 0 and i % log_every == 0:
+                    correct = (y_hat.reshape(y.shape[0], -1).argmax(1) == y.argmax(1)).sum().item()
+                    print(f"Epoch: {epoch + 1}, Batch: {i + 1}, Device: [{rank}, {local_rank}], Loss: {float(loss)}, "
+                          f"Accuracy: {100.0 * correct / y.size(0):.4f}%")
+                n_steps += 1
+                if max_steps is not None and n_steps >= max_steps:
+                    break
+            if rank == 0 and local_rank == 0 and checkpoint_path:
+                os.makedirs(os.path.dirname(os.path.abspath(checkpoint_path)), exist_ok=True)
+                torch.save(model.state_dict(), checkpoint_path)                                            # cls:105-107
+            if scheduler is not None:
+                scheduler.step()                                                                           # cls:108-109
+            if max_steps is not None and n_steps >= max_steps:
+                break
+    finally:
+        if isinstance(optimizer, FusedClipAdamW):
+            optimizer.close()
+    model = model.to("cpu")                                                                                # cls:112
+    if destroy_process_group and dist.is_initialized():
+        dist.destroy_process_group()
+    return model

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CALM_ABI_VERSION 4
+#define CALM_ABI_VERSION 5
 
 #define CALM_E_INVAL   (-1)   /* null pointer / negative size                 */
 #define CALM_E_LAYOUT  (-2)   /* stride pattern the kernel cannot address     */
@@ -354,6 +354,15 @@ int calm_optim_step(const calm_optim_tensor* tensors_dev, int32_t n_tensors, con
  * ------------------------------------------------------------------------------------- */
 int calm_collate_mix(const uint8_t* img_u8, const uint8_t* flip, float* out, int32_t B, int32_t H, int32_t W,
                      int32_t mode, float lam, const int32_t* box, const float* mean, const float* std, void* stream);
+/* ABI v5 — the same pass with the per-sample RandomCrop((H, W)) of distributed_trainer_cls.py:130 folded in and, optionally,
+ * the output written directly as the row tokens the first Block consumes (Vi_Tools_CNN_less_V2.py:389-391):
+ *   img_u8 [B,3,Hs,Ws] (the loader's Resize((256,256)) output, cls:129), crop_yx: DEVICE int32 [B,2] top-left corners
+ *   (y0 in [0, Hs-H], x0 in [0, Ws-W]; NULL needs Hs == H, Ws == W); flips, mix and box act on the cropped window (the
+ *   order of the reference's transform list: crop, ..., flip, ..., Normalize, then the batch-level CutMix / MixUp);
+ *   out_tokens == 0: out [B,3,H,W];  != 0: out [B,H,3W] with out[b,i,3j+c] = image[b,c,i,j] (needs H == W for the model). */
+int calm_collate_crop_mix(const uint8_t* img_u8, int32_t Hs, int32_t Ws, const int32_t* crop_yx, const uint8_t* flip,
+                          float* out, int32_t B, int32_t H, int32_t W, int32_t out_tokens, int32_t mode, float lam,
+                          const int32_t* box, const float* mean, const float* std, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Tokenisation (bit-exact index work).

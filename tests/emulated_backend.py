@@ -143,6 +143,18 @@ class EmulatedBackend:
             x[..., y1:y2, x1:x2] = xr[..., y1:y2, x1:x2]
         out.copy_(x)
 
+    def collate_crop_mix(self, img_u8, crop_yx, flip, out, mode, lam, box, mean, std, tokens=False):
+        B = img_u8.shape[0]
+        H, W = (out.shape[1], out.shape[2] // 3) if tokens else (out.shape[2], out.shape[3])
+        if crop_yx is None:
+            win = img_u8
+        else:
+            win = torch.stack([img_u8[b, :, int(crop_yx[b, 0]):int(crop_yx[b, 0]) + H, int(crop_yx[b, 1]):int(crop_yx[b, 1]) + W]
+                               for b in range(B)])
+        img = torch.empty(B, 3, H, W)
+        self.collate_mix(win, flip, img, mode, lam, box, mean, std)
+        out.copy_(img.permute(0, 2, 3, 1).reshape(B, H, 3 * W) if tokens else img)
+
     def optim_plan(self, records):
         import numpy as np
         plan = EmuPlan([])

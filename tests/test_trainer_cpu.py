@@ -1,0 +1,190 @@
+"""Host logic of the launcher that replaces distributed_trainer_cls.py's Spark job (no GPU: the model's kernels are the
+torch emulation of the C-ABI):
+  * FusedClipAdamW is a torch.optim.Optimizer: CosineAnnealingLR(optimizer, T_max, eta_min=1e-6) of cls:52 drives its
+    learning rate exactly as it drives torch's AdamW;
+  * the spectral-norm deferral mark has an owner: a second optimizer over the same model takes it over, the
+    dropped first one's finalizer leaves it alone, and the surviving optimizer's step equals torch's clip + AdamW;
+  * the CutMix / MixUp soft-label collate against hand-derived vectors (tests/golden/mix_vectors.json);
+  * `train()` end to end on two gloo ranks: rank sharding (DistributedSampler seed 2006), cosine schedule per epoch,
+    rank-0 checkpoint with the reference's state-dict keys, replicas bit-identical."""
+import gc
+import json
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import calm_vit_dte_amd as calm  # noqa: E402
+from emulated_backend import EmulatedBackend  # noqa: E402
+from test_host_logic_cpu import build_model  # noqa: E402
+from importlib import import_module  # noqa: E402
+
+trainer = import_module("calm_vit_dte_amd.trainer")
+VEC = json.load(open(os.path.join(ROOT, "tests", "golden", "mix_vectors.json")))
+
+
+def _batch(seed=0, B=4):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(B, 3, 32, 32, generator=g), torch.softmax(torch.randn(B, 10, generator=g), 1)
+
+
+def test_cosine_schedule_drives_the_fused_optimizer_like_torch_adamw():
+    m = build_model("tiny32_cls", None).train()
+    x, y = _batch()
+    with calm.backend.use_backend(EmulatedBackend()):
+        opt = trainer.FusedClipAdamW(m)
+        assert isinstance(opt, torch.optim.Optimizer) and len(opt.param_groups) == 1
+        ref = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=3.1e-3, weight_decay=0.02, betas=(0.9, 0.98))
+        s_f = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=5, eta_min=1e-6)
+        s_r = torch.optim.lr_scheduler.CosineAnnealingLR(ref, T_max=5, eta_min=1e-6)
+        step = trainer.TrainStep(m, opt)
+        try:
+            for _ in range(6):
+                step(x, y)
+                ref.step()
+                s_f.step()
+                s_r.step()
+                assert opt.lr == ref.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
+            assert abs(opt.lr - s_r.get_last_lr()[0]) == 0.0
+        finally:
+            opt.close()
+
+
+def test_second_optimizer_takes_the_deferral_over_and_steps_like_torch():
+    """Build two optimizers on one model, drop the first: the survivor's step must equal clip_grad_norm_ + AdamW on a
+    model whose backward corrects the spectral-norm gradients itself (no double correction, no lost correction)."""
+    from calm_vit_dte_amd import ops
+    x, y = _batch(1)
+    with calm.backend.use_backend(EmulatedBackend()):
+        m_ref = build_model("tiny32_cls", None).train()
+        m = build_model("tiny32_cls", None).train()
+        m.load_state_dict(m_ref.state_dict())
+        opt_ref = trainer.make_optimizer(m_ref)
+        step_ref = trainer.TrainStep(m_ref, opt_ref)
+        first = trainer.FusedClipAdamW(m)
+        second = trainer.FusedClipAdamW(m)                # takes the marks over
+        marked = [p for p in m.parameters() if getattr(p, ops.DEFER_ATTR, None) is not None]
+        assert marked and all(getattr(p, ops.DEFER_ATTR) == second._token for p in marked)
+        del first
+        gc.collect()                                      # the dropped optimizer's finalizer runs here
+        assert all(getattr(p, ops.DEFER_ATTR, None) == second._token for p in marked)
+        step = trainer.TrainStep(m, second)
+        try:
+            for _ in range(2):
+                l_ref, _ = step_ref(x, y)
+                l, _ = step(x, y)
+                assert abs(float(l) - float(l_ref)) < 1e-5
+            sd, sd_ref = m.state_dict(), m_ref.state_dict()
+            worst = max(float((sd[k] - sd_ref[k]).abs().max()) for k in sd)
+            assert worst < 2e-5, worst
+        finally:
+            second.close()
+        assert not any(hasattr(p, ops.DEFER_ATTR) for p in m.parameters())
+        stale = trainer.FusedClipAdamW(m)
+        newest = trainer.FusedClipAdamW(m)
+        with pytest.raises(RuntimeError):                 # a superseded optimizer refuses to step
+            trainer.TrainStep(m, stale)(x, y)
+        newest.close()
+        stale.close()
+
+
+@pytest.mark.parametrize("case", VEC["cutmix_boxes"], ids=lambda c: f"{c['H']}x{c['W']}_lam{c['lam']}")
+def test_cutmix_box_matches_hand_derived_vectors(case):
+    box, lam = trainer.SoftMixCollate.cutmix_box(case["lam"], case["cx"], case["cy"], case["H"], case["W"])
+    assert list(box) == case["box_y1y2x1x2"]
+    assert abs(lam - case["lam_corrected"]) < 1e-12
+
+
+def test_mixup_and_cutmix_batches_match_hand_derived_vectors():
+    bc = VEC["batch_case"]
+    x = torch.tensor(bc["x"], dtype=torch.float32)
+    labels = torch.tensor(bc["labels"])
+    col = trainer.SoftMixCollate(num_classes=bc["num_classes"])
+    out, y = col.mix(x, labels, 1, bc["mixup"]["lam"])
+    assert torch.allclose(out[0, 0], torch.tensor(bc["mixup"]["out_sample0_channel0"]), atol=1e-6)
+    assert torch.allclose(out[1, 2], torch.tensor(bc["mixup"]["out_sample1_channel2"]), atol=1e-6)
+    assert torch.allclose(y, torch.tensor(bc["mixup"]["y"]), atol=1e-7)
+    out, y = col.mix(x, labels, 2, bc["cutmix"]["lam_corrected"], tuple(bc["cutmix"]["box_y1y2x1x2"]))
+    assert torch.equal(out[0, 1], torch.tensor(bc["cutmix"]["out_sample0_channel1"]))
+    assert torch.equal(out[2, 0], torch.tensor(bc["cutmix"]["out_sample2_channel0"]))
+    assert torch.allclose(y, torch.tensor(bc["cutmix"]["y"]), atol=1e-7)
+    # the emulation of the device collate (what the GPU kernel is checked against) agrees on the same decisions
+    emu = EmulatedBackend()
+    u8 = (torch.arange(3 * 3 * 2 * 2).reshape(3, 3, 2, 2) * 7 % 256).to(torch.uint8)
+    dev = torch.empty(3, 3, 2, 2)
+    emu.collate_mix(u8, None, dev, 2, 0.75, (0, 1, 1, 2), (0.0, 0.0, 0.0), (1.0, 1.0, 1.0))
+    host, _ = col.mix(u8.float() / 255.0, labels, 2, 0.75, (0, 1, 1, 2))
+    assert torch.allclose(dev, host, atol=1e-7)
+
+
+class _TinySet(torch.utils.data.Dataset):
+    def __init__(self, n=16):
+        g = torch.Generator().manual_seed(7)
+        self.x = torch.randn(n, 3, 32, 32, generator=g)
+        self.y = torch.randint(0, 10, (n,), generator=g)
+
+    def __len__(self):
+        return len(self.y)
+
+    def __getitem__(self, i):
+        return self.x[i], int(self.y[i])
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _train_worker(rank, world, port, outdir, optimizer_kind):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    torch.manual_seed(50 + rank)                          # ranks start different: the launcher must sync them
+    m = build_model("tiny32_cls", None).train()
+    if rank:
+        with torch.no_grad():
+            for p in m.parameters():
+                p.add_(0.01)
+    seen = []
+
+    class Spy(_TinySet):
+        def __getitem__(self, i):
+            seen.append(int(i))
+            return super().__getitem__(i)
+
+    with calm.backend.use_backend(EmulatedBackend()):
+        opt = "fused" if optimizer_kind == "fused" else trainer.make_optimizer(m)
+        out = trainer.train(m, opt, None, use_gpu=False, dataset=Spy(), epochs=2, batch_size=4, num_classes=10,
+                            checkpoint_path=os.path.join(outdir, "models", "model_cls.pth"), log_every=1000)
+    torch.save({"sd": out.state_dict(), "seen": seen}, os.path.join(outdir, f"rank{rank}.pt"))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("optimizer_kind", ["adamw", "fused"])
+def test_train_launcher_on_two_gloo_ranks(tmp_path, optimizer_kind):
+    mp.spawn(_train_worker, args=(2, _free_port(), str(tmp_path), optimizer_kind), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    for k in r0["sd"]:
+        assert torch.equal(r0["sd"][k], r1["sd"][k]), f"ranks diverged at {k}"
+    # DistributedSampler(shuffle=True, seed=2006): per epoch the two ranks see disjoint halves of the 16 samples
+    for e in range(2):
+        a, b = set(r0["seen"][8 * e:8 * e + 8]), set(r1["seen"][8 * e:8 * e + 8])
+        assert len(a) == len(b) == 8 and not (a & b)
+    g = torch.Generator().manual_seed(2006)               # epoch 0's permutation is the sampler's documented one
+    perm = torch.randperm(16, generator=g).tolist()
+    assert r0["seen"][:8] == perm[0::2] and r1["seen"][:8] == perm[1::2]
+    ck = torch.load(os.path.join(tmp_path, "models", "model_cls.pth"))
+    assert set(ck) == set(r0["sd"])                       # the reference's keys (weight_orig / _u / _v ...)
+    assert any(k.endswith("weight_orig") for k in ck)
+    for k in ck:
+        assert torch.equal(ck[k], r0["sd"][k])            # written after the last epoch's last step

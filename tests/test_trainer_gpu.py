@@ -420,3 +420,105 @@ def test_eval_loop_top1_accuracy(tmp_path):
     for pth in paths:
         with open(pth, "rb") as f:
             assert f.read(8) == b"\x89PNG\r\n\x1a\n"
+
+
+# ---- round 3: on-device crop + token layout of the collate, and the RCCL path on one GPU -------------------
+def test_device_collate_random_crop_and_row_token_output_against_hand_derived_vectors():
+    """calm_collate_crop_mix: RandomCrop window + flip + Normalize + CutMix / MixUp in one pass, written either as the
+    image [B,3,H,W] or directly as the row tokens [B,H,3W] of the first Block — against the emulation, against the
+    hand-derived vectors of tests/golden/mix_vectors.json (box from lam, roll-by-one partner, soft labels), and the
+    token form bit-equal to image_to_rows of the image form."""
+    import json
+    import os
+    from emulated_backend import EmulatedBackend
+    hip, emu = calm.backend.get_backend(), EmulatedBackend()
+    vec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mix_vectors.json")))
+    g = torch.Generator().manual_seed(3)
+    B, Hs, Ws, H, W = 6, 40, 48, 32, 32
+    img = torch.randint(0, 256, (B, 3, Hs, Ws), generator=g, dtype=torch.uint8)
+    crop = torch.stack([torch.randint(0, Hs - H + 1, (B,), generator=g), torch.randint(0, Ws - W + 1, (B,), generator=g)], 1).int()
+    flip = torch.tensor([1, 0, 1, 1, 0, 0], dtype=torch.uint8)
+    mean, std = trainer.DeviceCollate.MEAN, trainer.DeviceCollate.STD
+    for mode, lam, box in ((1, 0.3, None), (2, 0.75, (3, 20, 5, 30)), (0, 1.0, None)):
+        ref = torch.empty(B, 3, H, W)
+        emu.collate_crop_mix(img, crop, flip, ref, mode, lam, box, mean, std)
+        out = torch.empty(B, 3, H, W, device="cuda")
+        tok = torch.empty(B, H, 3 * W, device="cuda")
+        hip.collate_crop_mix(img.cuda(), crop.cuda(), flip.cuda(), out, mode, lam, box, mean, std)
+        hip.collate_crop_mix(img.cuda(), crop.cuda(), flip.cuda(), tok, mode, lam, box, mean, std, tokens=True)
+        assert rel_err(out, ref) < 1e-6
+        rows = torch.empty(B, H, 3 * W, device="cuda")
+        hip.image_to_rows(out, rows, B, H)
+        assert torch.equal(tok, rows)                                    # index work: bit-exact
+    # the hand-derived batch: identity normalisation, values scaled into uint8
+    bc = vec["batch_case"]
+    x = (torch.tensor(bc["x"]) * 10).round().to(torch.uint8)             # 0 .. 223, exact in uint8
+    labels = torch.tensor(bc["labels"]).cuda()
+    col = trainer.DeviceCollate(num_classes=bc["num_classes"])
+    col.MEAN, col.STD = (0.0, 0.0, 0.0), (1.0, 1.0, 1.0)
+    noflip = torch.zeros(3, dtype=torch.uint8)
+    out, y = col(x.cuda(), labels, decisions=(1, bc["mixup"]["lam"], None, noflip))
+    exp = torch.tensor(bc["mixup"]["out_sample0_channel0"]) * 10 / 255.0
+    assert torch.allclose(out[0, 0].cpu(), exp, atol=1e-6)
+    assert torch.allclose(y.cpu(), torch.tensor(bc["mixup"]["y"]), atol=1e-7)
+    out, y = col(x.cuda(), labels, decisions=(2, bc["cutmix"]["lam_corrected"], tuple(bc["cutmix"]["box_y1y2x1x2"]), noflip))
+    assert torch.allclose(out[0, 1].cpu(), torch.tensor(bc["cutmix"]["out_sample0_channel1"]) * 10 / 255.0, atol=1e-6)
+    assert torch.allclose(out[2, 0].cpu(), torch.tensor(bc["cutmix"]["out_sample2_channel0"]) * 10 / 255.0, atol=1e-6)
+    assert torch.allclose(y.cpu(), torch.tensor(bc["cutmix"]["y"]), atol=1e-7)
+    # the cropped, tokenised batch really is what the model consumes
+    col2 = trainer.DeviceCollate(num_classes=10, seed=1)
+    big = torch.randint(0, 256, (4, 3, 36, 36), dtype=torch.uint8, device="cuda")
+    lab = torch.tensor([1, 2, 3, 4], device="cuda")
+    toks, y = col2(big, lab, crop=(32, 32), tokens=True)
+    assert toks.shape == (4, 32, 96) and y.shape == (4, 10) and abs(float(y.sum()) - 4.0) < 1e-5
+
+
+def test_bucketed_reducer_on_rccl_world_of_one_is_bit_identical_to_no_reducer():
+    """The 8-GPU job's gradient exchange executed on this one GPU: init_process_group('nccl', world_size=1) loads and
+    runs librccl, ReduceOp.AVG inside the collective, the side-stream waits and the bucket views; three fused training
+    steps must leave exactly the parameters of the reducer-less run (RCCL had never executed)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
+                            device_id=torch.device("cuda", 0))
+    try:
+        assert dist.get_backend() == "nccl"
+        name = "nano48_cls"
+        cfg, x, y = _batch(name)
+        g = load_golden(name)
+        results = []
+        for use_reducer in (False, True):
+            m = build_model(name, g, "cuda").train()
+            calm.ops.set_noise_override(W.NoiseStream(11))
+            opt = trainer.FusedClipAdamW(m)
+            red = trainer.BucketedGradReducer(m, bucket_mb=1, tail_mb=1, force=True) if use_reducer else None
+            if red is not None:
+                assert red.enabled and red.avg_in_collective and len(red.buckets) >= 2
+            step = trainer.TrainStep(m, opt, red)
+            try:
+                losses = [float(step(x.cuda(), y.cuda())[0]) for _ in range(3)]
+            finally:
+                opt.close()
+                calm.ops.set_noise_override(None)
+            torch.cuda.synchronize()
+            results.append((losses, {k: v.clone() for k, v in m.state_dict().items()}))
+        (l0, sd0), (l1, sd1) = results
+        assert l0 == l1
+        for k in sd0:
+            assert torch.equal(sd0[k], sd1[k]), k
+        # and a plain RCCL collective on the side-stream pattern of the reducer
+        t = torch.arange(1 << 20, device="cuda", dtype=torch.float32)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            w = dist.all_reduce(t, op=dist.ReduceOp.AVG, async_op=True)
+            w.wait()
+        torch.cuda.current_stream().wait_stream(side)
+        assert float(t[12345]) == 12345.0
+    finally:
+        dist.destroy_process_group()
