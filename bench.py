@@ -240,6 +240,23 @@ def host_cpu_info():
     return model, max(1, len(cores) or len(aff)), len(aff)
 
 
+def cpu_quota():
+    """CPUs this container may actually use at once (cgroup v2 cpu.max / v1 cfs quota), or None when unlimited: the
+    affinity mask of a GPU box lists every CPU of the host, but the box's share is a quota (16 for one GPU), and more
+    threads than that are time-sliced — 128 threads measured 8x SLOWER than 16 on such a box."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else max(1, int(round(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else max(1, int(round(q / per)))
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(wl, budget_s=30.0):
     """CPU oracle (port of the reference path) fwd+bwd+AdamW on a bounded sample of the workload, as BASELINE.md
     section 3 prescribes: fp32, one thread per PHYSICAL core of the affinity mask (never more: oversubscription cost 20x
@@ -247,7 +264,9 @@ def cpu_baseline(wl, budget_s=30.0):
     from oracle import calm_oracle as O
     import calm_vit_dte_amd as calm
     W = calm.synthetic_weights
-    cpu_model, threads, logical = host_cpu_info()
+    cpu_model, physical, logical = host_cpu_info()
+    quota = cpu_quota()
+    threads = physical if quota is None else max(1, min(physical, quota))
     torch.set_num_threads(threads)
     cfg = O.ViTConfig(force_reduce=False, generate=False, **wl["kw"])
     P = {k: torch.from_numpy(v) for k, v in W.make_params(O.vit_param_shapes(cfg), WEIGHT_SEED).items()}
@@ -276,10 +295,10 @@ def cpu_baseline(wl, budget_s=30.0):
         step()
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
-    return {"value": round(bs / med, 3), "unit": "images/sec", "cores": threads, "affinity": logical, "cpu_model": cpu_model,
-            "kind": "port",
-            "sample": f"oracle fwd+bwd+AdamW fp32, bs={bs}, {len(times)} timed steps after 2 warm-up, median; "
-                      f"{threads} threads = physical cores of the {logical}-CPU affinity mask"}
+    return {"value": round(bs / med, 3), "unit": "images/sec", "cores": threads, "physical_cores": physical,
+            "affinity": logical, "cpu_quota": quota, "cpu_model": cpu_model, "kind": "port",
+            "sample": f"oracle fwd+bwd+AdamW fp32, bs={bs}, {len(times)} timed steps after 2 warm-up, median; threads = "
+                      f"min(physical cores in the affinity mask = {physical}, cgroup CPU quota = {quota})"}
 
 
 def self_launch(n):

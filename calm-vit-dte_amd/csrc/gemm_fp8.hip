@@ -147,9 +147,16 @@ __device__ __forceinline__ float ldq(const void* p, long i, int type) {
 __global__ __launch_bounds__(QNT) void amax_kernel(const void* __restrict__ x, int x_type, long n, unsigned* __restrict__ amax_bits) {
     __shared__ float red[4];
     float m = 0.f;
-    for (long i = (long)blockIdx.x * QNT + threadIdx.x; i < n; i += (long)gridDim.x * QNT) m = fmaxf(m, fabsf(ldq(x, i, x_type)));
+    bool bad = false;                                        // fmaxf drops NaN: a non-finite input must stay visible
+    for (long i = (long)blockIdx.x * QNT + threadIdx.x; i < n; i += (long)gridDim.x * QNT) {
+        const float a = fabsf(ldq(x, i, x_type));
+        bad = bad || !(a <= 3.402823466e38f);                // NaN or infinity
+        m = fmaxf(m, a);
+    }
     m = block_max_256(m, red);
     if (threadIdx.x == 0) atomicMax(amax_bits, __float_as_uint(m));
+    // (as unsigned bits a quiet NaN compares above every finite value and above +inf: it survives the atomic max)
+    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicMax(amax_bits, 0x7FC00000u);
 }
 
 // q = fp8(x * FP8_MAX / amax); state[1] = amax / FP8_MAX (the factor the GEMM epilogue multiplies back in).
@@ -160,7 +167,10 @@ __global__ __launch_bounds__(QNT) void quant_kernel(const void* __restrict__ x, 
     constexpr float FMAX = BF8 ? 57344.0f : 448.0f;
     const float amax = state[0];
     const float sc = amax > 0.f ? FMAX / amax : 1.0f;
-    if (blockIdx.x == 0 && threadIdx.x == 0) state[1] = amax > 0.f ? amax / FMAX : 1.0f;
+    // a NaN / infinity among the inputs (amax is then NaN): the dequantisation factor becomes NaN, so every output of the
+    // product that consumes this tensor is NaN — the clamp below would otherwise turn the offending element into a
+    // finite -FMAX and hide the divergence from the loss and from GradScaler's inf check
+    if (blockIdx.x == 0 && threadIdx.x == 0) state[1] = !(amax <= 3.402823466e38f) ? __uint_as_float(0x7FC00000u) : amax > 0.f ? amax / FMAX : 1.0f;
     const long n4 = n >> 2;                                  // n % 4 == 0 (checked by the host)
     for (long i = (long)blockIdx.x * QNT + threadIdx.x; i < n4; i += (long)gridDim.x * QNT) {
         // clamped: amax * (FMAX / amax) may round a hair above FMAX, which the conversion would turn into NaN

@@ -15,7 +15,7 @@ from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
 from .backend import ACT_GELU, ACT_GELU_BWD, ACT_NONE, act_dtype, bf16_pipeline, fp8_linears, get_backend
-from .spectral_norm import W16_ATTR
+from .spectral_norm import W16_ATTR, W16_GEN_ATTR
 
 # The reference calls the model under autocast(bfloat16) (distributed_trainer_cls.py:84): custom_fwd records the
 # autocast state of the forward call, custom_bwd re-establishes it around backward (autograd runs backward outside the
@@ -55,6 +55,19 @@ def _wop(w):
         if w16 is not None and w16.shape == w.shape:
             return w16
     return w
+
+
+def _wgen(*ws):
+    """Generation of the bf16 copies of `ws` at forward time (None for weights without a copy)."""
+    return tuple(getattr(w, W16_GEN_ATTR, None) for w in ws)
+
+
+def _check_wgen(gen, *ws):
+    """Backward must see the bf16 weight copies its forward used: they are rewritten in place by every forward."""
+    if gen != _wgen(*ws):
+        raise RuntimeError("one of the bf16 weight copies needed for gradient computation has been rewritten by a later "
+                           "forward (the copies are refreshed in place at the start of every forward): run backward "
+                           "before the next forward of the same model")
 
 
 class _ZeroArena:
@@ -290,6 +303,7 @@ class SNLinearFn(Function):
                      pre=pre.view(-1, N) if pre is not None else None)
         ctx.act = act
         ctx.wop = wop
+        ctx.wgen = _wgen(w)
         ctx.defer = _deferred(w)
         ctx.has_bias = bias is not None
         ctx.has_res = residual is not None
@@ -303,6 +317,7 @@ class SNLinearFn(Function):
     def backward(ctx, dy):
         be = get_backend()
         x2, w, ls, u, v, sigma, pre = ctx.saved_tensors
+        _check_wgen(ctx.wgen, w)
         N, K = w.shape
         dy2 = _c(dy).reshape(-1, N)
         if ctx.act == ACT_GELU:
@@ -358,6 +373,7 @@ class SNLinearGroupFn(Function):
                 inv_scale=sigmas, split_k=1)
         ctx.n = n
         ctx.wops = wops
+        ctx.wgen = _wgen(*ws)
         ctx.defer = [_deferred(w) for w in ws]
         ctx.xshape = x.shape
         ctx.save_for_backward(x2, *wuvs)
@@ -371,6 +387,7 @@ class SNLinearGroupFn(Function):
         x2, *wuvs = ctx.saved_tensors
         n = ctx.n
         ws, us, vs, sigmas = list(wuvs[0::4]), list(wuvs[1::4]), list(wuvs[2::4]), list(wuvs[3::4])
+        _check_wgen(ctx.wgen, *ws)
         N, K = ws[0].shape
         M = x2.shape[0]
         dy2 = [_c(d).reshape(-1, N) for d in dys]
@@ -419,6 +436,7 @@ class MlpFn(Function):
             _lin_fwd(be, x2, wop1, s1, hg, bias=b1, act=ACT_GELU, pre=hp)
             _lin_fwd(be, hg, wop2, s2, out.view(-1, N), bias=b2, col_scale=ls, residual=res2)
         ctx.wops = (wop1, wop2)
+        ctx.wgen = _wgen(w1, w2)
         ctx.has_b1, ctx.has_b2, ctx.has_res = b1 is not None, b2 is not None, residual is not None
         ctx.defer = (_deferred(w1), _deferred(w2))
         ctx.xshape = x.shape
@@ -431,6 +449,7 @@ class MlpFn(Function):
     def backward(ctx, dout):
         be = get_backend()
         x2, hp, hg, w1, w2, ls, u1, v1, s1, u2, v2, s2 = ctx.saved_tensors
+        _check_wgen(ctx.wgen, w1, w2)
         N, Hd = w2.shape
         K = w1.shape[1]
         do2 = _c(dout).reshape(-1, N)
@@ -482,6 +501,7 @@ class SeqLinearFn(Function):
         be.gemm(wop, x, out, S2, D, S, (S, 1, 0, 0), (1, D, S * D, 0), (D, S2 * D, 0), batch=(B, 1), inv_scale=sigma)
         ctx.defer = _deferred(w)
         ctx.wop = wop
+        ctx.wgen = _wgen(w)
         ctx.save_for_backward(x, w, u, v, sigma)
         return out
 
@@ -491,6 +511,7 @@ class SeqLinearFn(Function):
     def backward(ctx, dy):
         be = get_backend()
         x, w, u, v, sigma = ctx.saved_tensors
+        _check_wgen(ctx.wgen, w)
         B, S, D = x.shape
         S2 = w.shape[0]
         dy = _c(dy)
@@ -661,6 +682,7 @@ class LatentMaskAttention16Fn(Function):
         ctx.H = H
         ctx.defer = (_deferred(w1), _deferred(w2))
         ctx.wops = (w1o, w2o)
+        ctx.wgen = _wgen(w1, w2)
         ctx.save_for_backward(q, k, v, out, R, hp, hg, Mk, MkT, lse, w1, w2, u1, v1, s1, u2, v2, s2)
         return out
 
@@ -670,6 +692,7 @@ class LatentMaskAttention16Fn(Function):
     def backward(ctx, dout):
         be = get_backend()
         q, k, v, out, R, hp, hg, Mk, MkT, lse, w1, w2, u1, v1, s1, u2, v2, s2 = ctx.saved_tensors
+        _check_wgen(ctx.wgen, w1, w2)
         w1o, w2o = ctx.wops
         H = ctx.H
         B, S, D = q.shape

@@ -14,6 +14,7 @@ import torch
 
 from .backend import bf16_pipeline, get_backend
 
+W16_GEN_ATTR = "_calm_w16_gen"
 W16_ATTR = "_calm_w16"      # on a weight_orig Parameter: its bf16 copy for this step (bf16 pipeline), read by ops._wop
 
 _scope_depth = 0
@@ -159,8 +160,13 @@ def _refresh_bf16_weights(root, layers):
         flat = torch.empty(n, dtype=torch.bfloat16, device=ws[0].device)
         views = [flat[o:o + w.numel()].view(w.shape) for o, w in zip(offs, ws)]
         plan = be.cast_plan([(w.detach().reshape(-1), v.view(-1)) for w, v in zip(ws, views)])
-        st = {"key": key, "flat": flat, "views": views, "plan": plan}
+        st = {"key": key, "flat": flat, "views": views, "plan": plan, "gen": 0}
         root.__dict__["_w16_state"] = st
     be.cast_run(st["plan"])
+    # the copies are rewritten IN PLACE by every forward and reach backward outside save_for_backward (no autograd
+    # version counter): a generation number lets a backward detect that a later forward has replaced the weights its
+    # forward multiplied with (forward, optimizer step, forward, then the first forward's backward)
+    st["gen"] += 1
     for w, v in zip(ws, st["views"]):
         setattr(w, W16_ATTR, v)
+        setattr(w, W16_GEN_ATTR, st["gen"])

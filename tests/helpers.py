@@ -30,7 +30,7 @@ CONFIGS = {
                                 seq_len_step=8, seq_len_reduce=160, out_features=1000, force_reduce=False, generate=False),
 }
 # BASELINE.json configs #3-#5: fixtures minted from the reference at batch 1 (golden_<name>_b1.npz)
-REAL_SIZE_CFGS = ["base224_cls", "base384_cls", "large224_cls"]
+REAL_SIZE_CFGS = ["small224_cls", "base224_cls", "base384_cls", "large224_cls"]
 # single reference VMLA_Blocks at the real head dims (golden_block_<name>.npz; kwargs as in make_golden.BLOCKS)
 BLOCK_FIXTURES = {
     "A_hd56": dict(heads=12, dim1=672, dim2=672, mean_var_hidden=240, seq_length=224, seq_len_reduce=80,

@@ -100,3 +100,17 @@ def test_large224_with_fp8_linears_within_stated_tolerance_of_reference_fixture(
     ref = float((torch.tensor(g["train/grad_norms"]).double() ** 2).sum()) ** 0.5
     got = sum(float(p.grad.double().pow(2).sum()) for p in m.parameters()) ** 0.5
     assert abs(got - ref) < 2e-2 * ref
+
+
+def test_fp8_quantiser_propagates_non_finite_inputs():
+    """A NaN / Inf activation entering an fp8 product must come out non-finite: amax keeps the NaN, the
+    dequantisation factor turns NaN, and so does every output of the GEMM that consumes the tensor."""
+    be = calm.backend.get_backend()
+    for poison in (float("nan"), float("inf")):
+        x = torch.randn(64, 128, device="cuda")
+        x[3, 5] = poison
+        q, dq = be.quantize_fp8(x, torch.float8_e4m3fn)
+        assert not torch.isfinite(dq).all()
+    x = torch.randn(64, 128, device="cuda")
+    q, dq = be.quantize_fp8(x, torch.float8_e4m3fn)
+    assert torch.isfinite(dq).all() and float(dq) > 0

@@ -366,3 +366,24 @@ def test_gemm_bf16_tensors_that_cannot_be_staged_take_the_generic_path():
     A = rnd(64, 64).bfloat16().cuda()
     with pytest.raises(RuntimeError):                       # bf16 tensors need the bf16 matrix pipe
         hip.gemm(A, rnd(64, 64).cuda(), C, 64, 64, 64, (64, 1, 0, 0), (64, 1, 0, 0), (64, 0, 0))
+
+
+def test_backward_after_a_later_forward_refuses_stale_bf16_weight_copies():
+    """The per-step bf16 weight copies are rewritten in place by every forward and reach backward outside
+    save_for_backward: a backward that runs after another forward must raise (as torch's in-place version check does)
+    instead of silently differentiating with the new weights."""
+    name = "nano48_cls"
+    g = load_golden(name)
+    m = build_model(name, g, "cuda").train()
+    cfg = CONFIGS[name]
+    x = torch.from_numpy(W.make_input((2, 3, cfg.seq_length, cfg.seq_length), 2)).cuda()
+    calm.backend.set_matmul_precision("bf16")
+    calm.ops.set_noise_override(W.NoiseStream(7))
+    try:
+        y1, _ = m(x)
+        y2, _ = m(x)                       # refreshes the copies: generation moves on
+        with pytest.raises(RuntimeError, match="bf16 weight copies"):
+            y1.sum().backward()
+        y2.sum().backward()                # the newest forward's backward is fine
+    finally:
+        calm.ops.set_noise_override(None)

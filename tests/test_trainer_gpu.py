@@ -508,9 +508,27 @@ def test_bucketed_reducer_on_rccl_world_of_one_is_bit_identical_to_no_reducer():
             torch.cuda.synchronize()
             results.append((losses, {k: v.clone() for k, v in m.state_dict().items()}))
         (l0, sd0), (l1, sd1) = results
-        assert l0 == l1
+        # (the backward itself is not bit-reproducible run to run — LayerNorm / RoPE weight gradients are atomic sums —
+        # so the two trainings agree to rounding; the exchange itself is checked for exactness below)
+        assert all(abs(a - b) <= 2e-6 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)
         for k in sd0:
-            assert torch.equal(sd0[k], sd1[k]), k
+            assert rel_err(sd1[k].float(), sd0[k].float()) < 2e-5, k
+        # the exchange alone, bit for bit: known gradients through the hooks -> buckets -> RCCL AVG -> bucket views
+        lin = torch.nn.Sequential(torch.nn.Linear(300, 500), torch.nn.Linear(500, 700), torch.nn.Linear(700, 10)).cuda()
+        red = trainer.BucketedGradReducer(lin, bucket_mb=1, tail_mb=1, force=True)
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        want = {}
+        for prm in lin.parameters():
+            prm.grad = torch.randn(prm.shape, generator=gen, device="cuda")
+            want[prm] = prm.grad.clone()
+        for prm in reversed(list(lin.parameters())):
+            red._hook(prm)                                   # what autograd's post-accumulate hooks do during backward
+        red.finish()
+        torch.cuda.synchronize()
+        for prm in lin.parameters():
+            assert torch.equal(prm.grad, want[prm])
+            assert any(prm.grad.data_ptr() >= b["flat"].data_ptr() and
+                       prm.grad.data_ptr() < b["flat"].data_ptr() + b["flat"].numel() * 4 for b in red.buckets)
         # and a plain RCCL collective on the side-stream pattern of the reducer
         t = torch.arange(1 << 20, device="cuda", dtype=torch.float32)
         side = torch.cuda.Stream()
