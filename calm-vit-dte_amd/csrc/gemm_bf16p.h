@@ -24,6 +24,10 @@
 #pragma once
 #include "gemm_common.h"
 
+#ifndef CALM_PIPE_PRIO_FLIP
+#define CALM_PIPE_PRIO_FLIP 0      // trading priority between the two waves of a SIMD once per k-step: measured +-0 (36.8k vs 36.9k cycles)
+#endif
+
 namespace calm_gemm_detail {
 
 typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
@@ -46,13 +50,29 @@ __device__ __forceinline__ void glds16(const void* base, unsigned voff, unsigned
     const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);           // (the builtin returns int:
     const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));   //  widen as unsigned)
     const unsigned long long bu = ((unsigned long long)hi << 32) | lo;
+    lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(bu), "s"(lds_dst) : "memory");
 }
+// wave-uniform 64-bit value as an SGPR pair (an "s" asm operand the compiler holds in VGPRs does not assemble)
+__device__ __forceinline__ unsigned long long pipe_uniform64(const void* p) {
+    const unsigned long long b64 = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+// lean form for the k-loop: `base` already uniform (pipe_uniform64, once per k-tile), M0 declared clobbered instead
+// of saved and restored — three instructions per piece
+__device__ __forceinline__ void glds16_u(unsigned long long base, unsigned voff, unsigned lds_dst) {
+    lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff), "s"(base), "s"(lds_dst) : "memory", "m0");
+}
 // the same with a full per-lane address (last k-tile of a reduction whose length is not a multiple of 64)
 __device__ __forceinline__ void glds16_addr(const void* addr, unsigned lds_dst) {
     unsigned keep;
+    lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
                  "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(addr), "s"(lds_dst) : "memory");
@@ -103,12 +123,12 @@ struct PStage {
     }
     // piece i (one LDS-DMA instruction of this wave) of the k-tile at `base` into the image at LDS byte `dst`;
     // k_left < 64: last k-tile of a reduction whose length is not a multiple of 64 — chunks past the end read zeros
-    template <int I>
-    __device__ __forceinline__ void issue_piece(unsigned dst, int wave, int lane, int k_left) {
+    template <int I, bool TAIL>
+    __device__ __forceinline__ void issue_piece(unsigned dst, int wave, int lane, int k_left, unsigned long long ubase) {
         const int q = wave + 8 * I;
         if (!(TOTAL % 8 == 0 || q < TOTAL)) return;
-        if (k_left >= PBK) {
-            glds16(base, off[I], dst + 1024u * q);
+        if constexpr (!TAIL) {
+            glds16_u(ubase, off[I], dst + 1024u * q);
         } else {
             const int kfirst = KC ? 8 * ((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) : q * (1024 / W) + lane / (W / 16);
             const char* a = kfirst < k_left ? base + off[I] : reinterpret_cast<const char*>(calm_zero_block);
@@ -566,42 +586,98 @@ __global__ __launch_bounds__(PTHREADS, 2) void gemm_bf16p_kernel(const GemmP p) 
             const char* __restrict__ ia = lds + st * PSTAGE;
             const char* __restrict__ ib = ia + PB_OFF;
             constexpr int NPA = StA::PER_WAVE, NPB = StB::PER_WAVE, NPT = NPA + NPB, PPG = (NPT + MT - 1) / MT;
-            auto stage_pieces = [&](auto gtag) __attribute__((always_inline)) {
+            const unsigned long long ua = pipe_uniform64(sa.base), ub = pipe_uniform64(sb.base);
+            auto stage_group = [&](auto gtag, auto tail_tag) __attribute__((always_inline)) {
                 constexpr int G = decltype(gtag)::value;
-                if (k_left) {
+                constexpr bool TAIL = decltype(tail_tag)::value;
+                {
                     if constexpr (G * PPG + 0 < NPT) {
                         constexpr int P0 = G * PPG + 0;
-                        if constexpr (P0 < NPA) sa.template issue_piece<P0>(dst, wave, lane, k_left);
-                        else sb.template issue_piece<P0 - NPA>(dst + PB_OFF, wave, lane, k_left);
+                        if constexpr (P0 < NPA) sa.template issue_piece<P0, TAIL>(dst, wave, lane, k_left, ua);
+                        else sb.template issue_piece<P0 - NPA, TAIL>(dst + PB_OFF, wave, lane, k_left, ub);
                     }
                     if constexpr (PPG > 1 && G * PPG + 1 < NPT && 1 < PPG) {
                         constexpr int P1 = G * PPG + 1;
-                        if constexpr (P1 < NPA) sa.template issue_piece<P1>(dst, wave, lane, k_left);
-                        else sb.template issue_piece<P1 - NPA>(dst + PB_OFF, wave, lane, k_left);
+                        if constexpr (P1 < NPA) sa.template issue_piece<P1, TAIL>(dst, wave, lane, k_left, ua);
+                        else sb.template issue_piece<P1 - NPA, TAIL>(dst + PB_OFF, wave, lane, k_left, ub);
                     }
                     if constexpr (PPG > 2 && G * PPG + 2 < NPT) {
                         constexpr int P2 = G * PPG + 2;
-                        if constexpr (P2 < NPA) sa.template issue_piece<P2>(dst, wave, lane, k_left);
-                        else sb.template issue_piece<P2 - NPA>(dst + PB_OFF, wave, lane, k_left);
+                        if constexpr (P2 < NPA) sa.template issue_piece<P2, TAIL>(dst, wave, lane, k_left, ua);
+                        else sb.template issue_piece<P2 - NPA, TAIL>(dst + PB_OFF, wave, lane, k_left, ub);
                     }
                     if constexpr (PPG > 3 && G * PPG + 3 < NPT) {
                         constexpr int P3 = G * PPG + 3;
-                        if constexpr (P3 < NPA) sa.template issue_piece<P3>(dst, wave, lane, k_left);
-                        else sb.template issue_piece<P3 - NPA>(dst + PB_OFF, wave, lane, k_left);
+                        if constexpr (P3 < NPA) sa.template issue_piece<P3, TAIL>(dst, wave, lane, k_left, ua);
+                        else sb.template issue_piece<P3 - NPA, TAIL>(dst + PB_OFF, wave, lane, k_left, ub);
                     }
                 }
             };
+            auto stage_pieces = [&](auto gtag) __attribute__((always_inline)) {
+                if (k_left >= PBK) stage_group(gtag, std::false_type{});
+                else if (k_left > 0) stage_group(gtag, std::true_type{});
+            };
             static_assert(PPG <= 4, "at most four staging pieces per MFMA group");
-            // fragment reads run one MFMA group ahead: while the NT products of (ks, i) issue, the A fragment of the
-            // next group is already on its way, and the B fragments of k-step 1 replace those of k-step 0 one by one
-            // behind their last use.  sched_barrier pins the order [staging pieces, prefetch read | MFMA group]: left
-            // alone, the scheduler sinks every prefetch behind the MFMA group in front of it to save registers.
+            // Fragment reads run AHEAD of the MFMAs that use them; sched_barrier pins the order [staging pieces, prefetch
+            // reads | MFMA group]: left alone, the scheduler sinks every prefetch behind the MFMA group in front of it to
+            // save registers, and every group then starts with an exposed LDS round trip.
+#ifndef CALM_PIPE_DEEP
+#define CALM_PIPE_DEEP 0      // measured on 57344 x 672 x 672: 36.9k vs 37.0k cycles per k-loop, at +40 VGPRs — off
+#endif
+            constexpr bool DEEP = CALM_PIPE_DEEP && MT * NT <= 28;    // registers for two full fragment sets beside the accumulators
+            if constexpr (DEEP) {
+                // k-step 1's fragments (MT + NT reads) are requested while k-step 0's MT NT products issue — a whole
+                // k-step of lookahead (an LDS read under load takes ~300 cycles, an MFMA group NT x 16): one exposed LDS
+                // latency per k-tile, the one right after the barrier
+                pbf16x8 a0[MT], b0[NT], a1[MT], b1[NT];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) b0[j] = fb.load(ib, j, 0);
+#pragma unroll
+                for (int i = 0; i < MT; ++i) a0[i] = fa.load(ia, i, 0);
+                constexpr int RPG = (MT + NT + MT - 1) / MT;          // k-step 1 reads issued per k-step 0 group
+                auto group0 = [&](auto itag) __attribute__((always_inline)) {
+                    constexpr int i = decltype(itag)::value;
+                    stage_pieces(std::integral_constant<int, i>{});
+#pragma unroll
+                    for (int r = 0; r < RPG; ++r) {
+                        constexpr int dummy = 0;
+                        const int idx = i * RPG + r;                  // compile-time after unrolling
+                        if (idx < NT) b1[idx] = fb.load(ib, idx, 1);
+                        else if (idx < NT + MT) a1[idx - NT] = fa.load(ia, idx - NT, 1);
+                        (void)dummy;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                };
+                group0(std::integral_constant<int, 0>{});
+                group0(std::integral_constant<int, 1>{});
+                if constexpr (MT > 2) group0(std::integral_constant<int, 2>{});
+                if constexpr (MT > 3) group0(std::integral_constant<int, 3>{});
+#pragma unroll
+                for (int i = 0; i < MT; ++i) {
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+            // (one group of lookahead: the A fragment of the next group, and the B fragments of k-step 1 replace those of
+            // k-step 0 one by one behind their last use)
             pbf16x8 bf[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) bf[j] = fb.load(ib, j, 0);
             pbf16x8 a_cur = fa.load(ia, 0, 0);
             auto group = [&](auto kstag, auto itag) __attribute__((always_inline)) {
                 constexpr int ks = decltype(kstag)::value, i = decltype(itag)::value;
+#if CALM_PIPE_PRIO_FLIP
+                // the two waves of a SIMD trade priority once per k-step: with age-based arbitration alone the older wave
+                // runs ahead, reaches the barrier early and leaves the younger one to finish the k-tile alone
+                if constexpr (i == 0) {
+                    if ((wave < 4) == (ks == 0)) __builtin_amdgcn_s_setprio(1);
+                    else __builtin_amdgcn_s_setprio(0);
+                }
+#endif
                 if constexpr (ks == 0) stage_pieces(std::integral_constant<int, i>{});
                 pbf16x8 a_next = a_cur;
                 if constexpr (i + 1 < MT) a_next = fa.load(ia, i + 1, ks);
@@ -623,6 +699,7 @@ __global__ __launch_bounds__(PTHREADS, 2) void gemm_bf16p_kernel(const GemmP p) 
             group(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
             if constexpr (MT > 2) group(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
             if constexpr (MT > 3) group(std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
+            }
             if (k_left) {
                 sa.advance();
                 sb.advance();
