@@ -369,8 +369,11 @@ def main():
         if args.graph:
             if world > 1:
                 raise SystemExit("--graph is single-GPU only")
-            opt = trainer.make_optimizer(model, capturable=True)
-            step = trainer.GraphedTrainStep(model, opt, x, y)
+            opt = trainer.make_optimizer(model, capturable=True) if args.torch_optim else trainer.FusedClipAdamW(model)
+            if autocast and precision != "fp8":
+                precision = "bf16"
+            step = trainer.GraphedTrainStep(model, opt, x, y, scaler=torch.amp.GradScaler("cuda") if autocast else None,
+                                            autocast_dtype=torch.bfloat16 if autocast else None)
             prof_steps = 0                                 # events cannot be recorded inside a replayed graph
         else:
             opt = trainer.make_optimizer(model) if args.torch_optim else trainer.FusedClipAdamW(model)
@@ -392,8 +395,11 @@ def main():
             step(x, y)
         sync()
         t0 = time.perf_counter()
+        host = 0.0
         for _ in range(steps):
+            h0 = time.perf_counter()
             loss, _ = step(x, y)
+            host += time.perf_counter() - h0              # host time to ENQUEUE the step (no synchronisation inside)
         sync()
         dt = time.perf_counter() - t0
         if world > 1:
@@ -402,6 +408,7 @@ def main():
             dt = float(t.item())
         res = {"workload": workload, "precision": precision, "batch": batch, "S": S, "wl": wl,
                "ms_per_step": 1e3 * dt / steps, "value": world * batch * steps / dt, "loss": float(loss),
+               "host_enqueue_ms": 1e3 * host / steps,
                "roofline": None, "attention": None}
 
         # dominant-kernel roofline: HIP events around every calm_gemm launch of prof_steps extra steps
@@ -480,6 +487,7 @@ def main():
                      "metric": "training images/sec (224^2, bs=256/GPU)", "value": round(r2["value"], 2), "unit": "images/sec",
                      "steps": 10, "warmup": 3, "ms_per_step": round(r2["ms_per_step"], 3), "dtype": PRECISION_INFO["bf16"][0],
                      "model_tflops": round(r2["value"] * r2["wl"]["gflop_img"] / 1e3, 2), "hbm_peak_gib": r2["hbm_peak_gib"],
+                     "host_enqueue_ms_per_step": round(r2["host_enqueue_ms"], 2),
                      "roofline": r2["roofline"], "attention": r2["attention"]}
 
     if rank == 0:
@@ -495,10 +503,11 @@ def main():
                        "parallelism": f"dp{world}", "world": dist.get_world_size() if dist.is_initialized() else 1,
                        "backend": dist.get_backend() if dist.is_initialized() else "none (single process)",
                        "loss": loss, "hipgraph": bool(args.graph),
-                       "optimizer": "torch clip_grad_norm_ + AdamW" if (args.torch_optim or args.graph)
+                       "optimizer": "torch clip_grad_norm_ + AdamW" if args.torch_optim
                        else "calm_optim_step (norm + clip + AdamW + spectral-norm grad correction, 3 launches)"},
             "model_tflops": round(value * wl["gflop_img"] / 1e3, 2),
             "hbm_peak_gib": main_res["hbm_peak_gib"],
+            "host_enqueue_ms_per_step": round(main_res["host_enqueue_ms"], 2),
             "roofline": roofline,
             "attention": attention if roofline is not None else None,
         }

@@ -144,6 +144,7 @@ class OptimPlan:
         self.n_chunks = len(chunk_tensor)
         self.chunk_dev = torch.tensor(chunk_tensor, dtype=torch.int32, device=dev)
         self.hosts = [torch.empty(rec.nbytes, dtype=torch.uint8).pin_memory() for _ in range(self.RING)]
+        self.graph_host = torch.empty(rec.nbytes, dtype=torch.uint8).pin_memory()   # the table a captured step copies from
         self.events = [None] * self.RING
         self.slot = 0
         self.uploaded = None                    # gradient pointers of the table now (being) copied to table_dev
@@ -155,6 +156,15 @@ class OptimPlan:
     def upload(self, grad_ptrs):
         """Stage this step's gradient pointers (numpy uint64 array) and enqueue their copy on the current stream."""
         if self.uploaded is not None and np.array_equal(self.uploaded, grad_ptrs):
+            return
+        if torch.cuda.is_current_stream_capturing():
+            # hipGraph capture (GraphedTrainStep): the gradients live in the graph's private pool, so these addresses are
+            # the ones every replay sees; the copy becomes a memcpy node out of a pinned buffer of its own that is never
+            # rewritten (no event bookkeeping: a captured event cannot be synchronised on)
+            self.rec["grad"] = grad_ptrs
+            self.graph_host.numpy()[:] = self.rec.view(np.uint8).reshape(-1)       # (pinned at construction: no allocation here)
+            self.table_dev.copy_(self.graph_host, non_blocking=True)
+            self.uploaded = grad_ptrs.copy()
             return
         k = self.slot
         if self.events[k] is not None:

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
     __shared__ __attribute__((aligned(16))) float d2s[H1 * H1 * PS];   // dL/d(h2 pre-activation) on 18x18
     __shared__ float wts[3 * CH];                                       // w0 (by [c][i]) / sigma
     __shared__ float red[BG * CH];
+    __shared__ __attribute__((aligned(16))) float g1s[T * T * PS];     // gelu'(h1 pre-activation) on the tile's own pixels
 
     const int tid = threadIdx.x, c2 = tid & 15, g = tid >> 4;
     const int c = 2 * c2;
@@ -213,13 +214,19 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
             if (tid + k * BW_NT < H1 * H1 * 3) dys[tid + k * BW_NT] = pred[k];
         __syncthreads();
         if (tile + gridDim.x < n_tiles) request(tile + gridDim.x);
-        // h1 on the 20x20 region
+        // h1 on the 20x20 region; on the tile's own 16x16 pixels the derivative gelu'(z) as well (value and derivative
+        // share their exponential): the conv0 backward below needs it, and recomputing z and a second GELU-class
+        // evaluation there cost more than keeping 256 x 32 floats in LDS
 #pragma unroll 2
         for (int p = g; p < H2 * H2; p += BG) {
-            const int yy = y0 - 2 + p / H2, xx = x0 - 2 + p % H2;
+            const int py = p / H2, px = p % H2;
+            const int yy = y0 - 2 + py, xx = x0 - 2 + px;
             const float in = (yy >= 0 && yy < S && xx >= 0 && xx < S) ? 1.f : 0.f;
             const f32x2 z = w0r[0] * xs[3 * p] + w0r[1] * xs[3 * p + 1] + w0r[2] * xs[3 * p + 2] + b0r;
-            st2(&h1s[p * PS + c], gelu2(z) * in);
+            f32x2 val, grad;
+            gelu2_both(z, val, grad);
+            st2(&h1s[p * PS + c], val * in);
+            if (py >= 2 && py < T + 2 && px >= 2 && px < T + 2) st2(&g1s[((py - 2) * T + px - 2) * PS + c], grad);
         }
         __syncthreads();
         // dL/dh2p on the 18x18 region (+ weight grads of conv4 / dwconv on the tile's own pixels)
@@ -266,8 +273,7 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
                     dh1 += w2r[ky * 3 + kx] * ld2(&d2s[((qy + 2 - ky) * H1 + qx + 2 - kx) * PS + c]);
             const int px = ((qy + 2) * H2 + qx + 2) * 3;
             const float x0v = xs[px], x1v = xs[px + 1], x2v = xs[px + 2];
-            const f32x2 z = w0r[0] * x0v + w0r[1] * x1v + w0r[2] * x2v + b0r;
-            const f32x2 dz = dh1 * gelu2_grad(z) * in;
+            const f32x2 dz = dh1 * ld2(&g1s[q * PS + c]) * in;
             st2(&h1s[q * PS + c], dz);
             a_gb0 += dz;
             a_g0[0] += dz * x0v; a_g0[1] += dz * x1v; a_g0[2] += dz * x2v;

@@ -508,18 +508,23 @@ class FusedClipAdamW(torch.optim.Optimizer):
 
 class GraphedTrainStep:
     """The same step captured once into a hipGraph and replayed: every kernel of the library only enqueues on the
-    current stream (no allocation, no host sync), so forward + loss + backward + clip + AdamW is one graph launch.
-    Removes the ~3000 host-side launches per step (the floor of small configurations).  Single-GPU only in this
-    revision; the optimizer must be created with capturable=True.  Inputs are copied into static buffers."""
+    current stream (no allocation, no host sync), so forward + loss + backward + unscale / clip / AdamW is one graph
+    launch — with the library's fused optimizer-side step (FusedClipAdamW: its step counter and plan live on the
+    device) or a capturable torch optimizer, with or without the reference trainer's autocast(bfloat16) + GradScaler
+    (the scale update is device arithmetic, see TrainStep._finish).  Removes the ~3000 host-side launches per step: the
+    host's share of a step drops from tens of milliseconds to one graph launch, which is what keeps 8 ranks on one
+    host from becoming host-bound.  Single-GPU in this revision (the bucketed all-reduce is not captured).  Inputs are
+    copied into static buffers.  A learning-rate scheduler acts on replays only for optimizers that read the rate from
+    the device; FusedClipAdamW takes it as a launch argument, so re-capture after changing it."""
 
-    def __init__(self, model, optimizer, example_x, example_y, max_norm=1.0, warmup=3):
-        self.inner = TrainStep(model, optimizer, None, max_norm=max_norm)
+    def __init__(self, model, optimizer, example_x, example_y, max_norm=1.0, warmup=3, scaler=None, autocast_dtype=None):
+        self.inner = TrainStep(model, optimizer, None, max_norm=max_norm, scaler=scaler, autocast_dtype=autocast_dtype)
         self.x = example_x.clone()
         self.y = example_y.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                     # warm-up on a side stream (allocator + lazy plans)
-            for _ in range(warmup):
+            for _ in range(max(warmup, 1 if scaler is not None else 0)):
                 self.inner(self.x, self.y)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()

@@ -540,3 +540,34 @@ def test_bucketed_reducer_on_rccl_world_of_one_is_bit_identical_to_no_reducer():
         assert float(t[12345]) == 12345.0
     finally:
         dist.destroy_process_group()
+
+
+def test_graph_captured_step_with_the_fused_optimizer_and_grad_scaler_equals_eager():
+    """The whole reference step — autocast(bfloat16) forward, scaled loss, backward, unscale + inf check + clip + AdamW
+    (calm_optim_step with its device step counter), scale update — captured once into a hipGraph and replayed, against
+    the same steps issued eagerly (VERDICT r2 #9: the fused optimizer inside the graph)."""
+    name = "tiny32_cls"
+    g = load_golden(name)
+    cfg, x, y = _batch(name, bs=8)
+    x, y = x.cuda(), y.cuda()
+    results = []
+    for graphed in (False, True):
+        m = build_model(name, g, "cuda").train()
+        opt = trainer.FusedClipAdamW(m)
+        scaler = torch.amp.GradScaler("cuda", init_scale=1024.0)
+        try:
+            if graphed:
+                step = trainer.GraphedTrainStep(m, opt, x, y, warmup=1, scaler=scaler, autocast_dtype=torch.bfloat16)
+            else:
+                step = trainer.TrainStep(m, opt, None, scaler=scaler, autocast_dtype=torch.bfloat16)
+                step(x, y)                                # the graphed run's warm-up step
+            losses = [float(step(x, y)[0]) for _ in range(3)]
+            torch.cuda.synchronize()
+            assert opt.step_count == 4
+        finally:
+            opt.close()
+        results.append(({k: v.detach().clone() for k, v in m.state_dict().items()}, losses))
+    (sd_e, l_e), (sd_g, l_g) = results
+    assert all(abs(a - b) < 2e-2 * max(1.0, abs(a)) for a, b in zip(l_e, l_g)), (l_e, l_g)     # bf16 pipeline + atomics
+    worst = max(rel_err(sd_g[k].float(), sd_e[k].float()) for k in sd_e)
+    assert worst < 5e-2, worst
