@@ -513,7 +513,8 @@ class GraphedTrainStep:
     device) or a capturable torch optimizer, with or without the reference trainer's autocast(bfloat16) + GradScaler
     (the scale update is device arithmetic, see TrainStep._finish).  Removes the ~3000 host-side launches per step: the
     host's share of a step drops from tens of milliseconds to one graph launch, which is what keeps 8 ranks on one
-    host from becoming host-bound.  Single-GPU in this revision (the bucketed all-reduce is not captured).  Inputs are
+    host from becoming host-bound.  Single-GPU in this revision: capturing the bucketed RCCL all-reduce on its side stream
+    was tried in a world of one (torch 2.10 + RCCL 2.26.6) and crashes inside the capture, so N > 1 runs eagerly.  Inputs are
     copied into static buffers.  A learning-rate scheduler acts on replays only for optimizers that read the rate from
     the device; FusedClipAdamW takes it as a launch argument, so re-capture after changing it."""
 
