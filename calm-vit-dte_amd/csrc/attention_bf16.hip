@@ -159,33 +159,47 @@ __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void at
 
     f32x4v acc[NJ];
     bf16x8 Rf[NP];                       // R^T (then the mask) of this wave's queries as packed B fragments
+#ifdef ATT16_STAMP
+    const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
 
-    // ================= phase 1: R^T[j,i] = sum_c K_all[j,c] Q_all[i,c], 32 columns per step =================
+    // ================= phase 1: R^T[j,i] = sum_c K_all[j,c] Q_all[i,c], 64 columns per step =================
+    // (round 3: 64 instead of 32 columns per step — every step ends in a barrier behind which the next chunk's global
+    // loads are waited for, and its 14 MFMAs per wave are far shorter than that latency: in-kernel stamps gave 3.7k cycles
+    // per 32-column step at S = 224, i.e. the phase is a chain of exposed load latencies; half as many links)
     {
 #pragma unroll
         for (int t = 0; t < NJ; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
-        constexpr int LDK = ld_rt(32);
-        constexpr int NV = (SP * 8 + NTH - 1) / NTH;
+        constexpr int CW = 64;
+        constexpr int LDK = ld_rt(CW);
+        constexpr int NV = (SP * (CW / 4) + NTH - 1) / NTH;
         __bf16* img = smem16;
-        const int nch = (D + 31) / 32;
+        const int nch = (D + CW - 1) / CW;
         BlockStage<NV, NTH> st;
-        st.load(kb, D, S, D, SP, 32);
-        bf16x8 bq_next = row_frag(qrow, 0, g, D);
+        st.load(kb, D, S, D, SP, CW);
+        bf16x8 bq_next[CW / 32];
+#pragma unroll
+        for (int ks = 0; ks < CW / 32; ++ks) bq_next[ks] = row_frag(qrow, 32 * ks, g, D);
 #pragma unroll 1
         for (int c = 0; c < nch; ++c) {
             __syncthreads();                                         // the previous chunk's reads are done
-            st.store(img, LDK, SP, 32);
-            const bf16x8 bq = bq_next;
+            st.store(img, LDK, SP, CW);
+            bf16x8 bq[CW / 32];
+#pragma unroll
+            for (int ks = 0; ks < CW / 32; ++ks) bq[ks] = bq_next[ks];
             __syncthreads();
             if (c + 1 < nch) {                                       // next chunk's loads fly under this chunk's MFMAs
-                st.load(kb + 32 * (c + 1), D, S, D - 32 * (c + 1), SP, 32);
-                bq_next = row_frag(qrow, 32 * (c + 1), g, D);
+                st.load(kb + CW * (c + 1), D, S, D - CW * (c + 1), SP, CW);
+#pragma unroll
+                for (int ks = 0; ks < CW / 32; ++ks) bq_next[ks] = row_frag(qrow, CW * (c + 1) + 32 * ks, g, D);
             }
 #pragma unroll
-            for (int t = 0; t < NJ; ++t) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(img + (16 * t + c16) * LDK + 8 * g);
-                acc[t] = MFMA_BF16(a, bq, acc[t]);
-            }
+            for (int ks = 0; ks < CW / 32; ++ks)
+#pragma unroll
+                for (int t = 0; t < NJ; ++t) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(img + (16 * t + c16) * LDK + 32 * ks + 8 * g);
+                    acc[t] = MFMA_BF16(a, bq[ks], acc[t]);
+                }
         }
         __bf16* Rrow = p.R + ((long)b * S + q_ld) * S;
 #pragma unroll
@@ -197,6 +211,9 @@ __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void at
         }
     }
 
+#ifdef ATT16_STAMP
+    const unsigned long long ts1 = __builtin_amdgcn_s_memtime();
+#endif
     // ================= phase 2: M^T = W2 gelu(W1 R^T + b1) + b2, 32 hidden units per step =================
     {
         const float inv1 = 1.0f / p.s1[0], inv2 = 1.0f / p.s2[0];
@@ -280,6 +297,9 @@ __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void at
         if constexpr (!KEEP_MASK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // own mask stores before the re-reads
     }
 
+#ifdef ATT16_STAMP
+    const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
+#endif
     // ================= phase 3: per head  softmax(scale K_h Q_h^T + M^T),  O^T = V_h^T P^T =================
     constexpr int hdp = HDP, LDH = ld_rt(HDP), nks = HDP / 32, ndt = HDP / 16;
     // K_h / V_h of the NEXT head are fetched into registers while this head computes — where both images are resident
@@ -295,6 +315,9 @@ __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void at
         sk.load(kb, D, S, hd, SP, hdp);
         sv.load(vb, D, S, hd, SP, hdp);
     }
+    bf16x8 bq_pre[nks];                  // this lane's q fragments of the next head: their global latency under the current head
+#pragma unroll
+    for (int ks = 0; ks < nks; ++ks) bq_pre[ks] = row_frag(qrow, 32 * ks, g, hd);
 #pragma unroll 1
     for (int h = 0; h < p.H; ++h) {
         __syncthreads();                                             // previous head's (or phase 2's) reads are done
@@ -309,11 +332,15 @@ __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void at
         for (int t = 0; t < NJ; ++t) acc[t] = (f32x4v){0.f, 0.f, 0.f, 0.f};
         bf16x8 bq[nks];
 #pragma unroll
-        for (int ks = 0; ks < nks; ++ks) bq[ks] = row_frag(qrow + h * hd, 32 * ks, g, hd);
+        for (int ks = 0; ks < nks; ++ks) bq[ks] = bq_pre[ks];        // requested one head ago (round 3)
         __syncthreads();
         if (PRE3 && h + 1 < p.H) {
             sk.load(kb + (h + 1) * hd, D, S, hd, SP, hdp);
             sv.load(vb + (h + 1) * hd, D, S, hd, SP, hdp);
+        }
+        if (h + 1 < p.H) {
+#pragma unroll
+            for (int ks = 0; ks < nks; ++ks) bq_pre[ks] = row_frag(qrow + (h + 1) * hd, 32 * ks, g, hd);
         }
 #pragma unroll
         for (int ks = 0; ks < nks; ++ks) {
@@ -390,6 +417,14 @@ __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void at
             if (q_ok && d < hd) *reinterpret_cast<bf16x4*>(orow + d) = pack4(o);
         }
     }
+#ifdef ATT16_STAMP
+    __syncthreads();
+    if (tid == 0 && blockIdx.x == 0) {       // diagnostic build only: phase cycles over the lse of the first queries of head 0
+        const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
+        float* d = p.lse + (long)b * p.H * S;
+        d[0] = (float)(ts1 - ts0); d[1] = (float)(ts2 - ts1); d[2] = (float)(ts3 - ts2);
+    }
+#endif
 }
 
 // MkT[b][key][query] = Mk[b][query][key] for the key-side backward pass (keys on the lanes there).  A pass of its own:
@@ -449,7 +484,7 @@ inline bool fwd_kv_shared(int S, int hd) {
 }
 inline size_t fwd_lds_bytes(int S, int hd) {
     const int NP = (S + 31) / 32, SP = 32 * NP, hdp = (hd + 31) / 32 * 32;
-    const size_t ph1 = (size_t)SP * ld_rt(32);
+    const size_t ph1 = (size_t)SP * ld_rt(64);
     const size_t ph2 = (size_t)32 * ld_pt(SP) + (size_t)SP * ld_pt(32);
     const size_t ph3 = (size_t)(fwd_kv_shared(S, hd) ? 1 : 2) * SP * ld_rt(hdp);
     size_t m = ph1 > ph2 ? ph1 : ph2;
