@@ -14,7 +14,7 @@ ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 F32 = 0
 ST_F32, ST_BF16, ST_FP8_E4M3, ST_FP8_E5M2 = 0, 1, 2, 3   # storage type of a tensor in HBM (CALM_ST_*)
 E_INVAL, E_LAYOUT, E_UNSUPP = -1, -2, -3      # CALM_E_*
-ABI_VERSION = 5          # CALM_ABI_VERSION of include/calm_vit.h
+ABI_VERSION = 6          # CALM_ABI_VERSION of include/calm_vit.h
 
 _p = C.c_void_p
 _i32 = C.c_int32
@@ -78,6 +78,7 @@ SIGNATURES = {
     "calm_build_info": (C.c_char_p, []),
     "calm_gemm": (_i32, [C.POINTER(GemmArgs), _p]),
     "calm_gemm_workspace_bytes": (_i64, [C.POINTER(GemmArgs)]),
+    "calm_gemm_set_option": (C.c_int, [_i32, _i32]),
     "calm_layernorm_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _f32, _i32, _p]),
     "calm_layernorm_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
     "calm_cast_chunk_elems": (_i32, []),

@@ -196,6 +196,15 @@ class HipBackend:
         self.lib = _lib.load()
 
     # ---- GEMM -------------------------------------------------------------------------
+    GEMM_OPT_PIPE, GEMM_OPT_PIPE32 = 0, 1
+
+    def gemm_set_option(self, option, value):
+        """calm_gemm_set_option (ABI v6): kernel-family switches of calm_gemm; returns the previous value."""
+        prev = self.lib.calm_gemm_set_option(int(option), int(value))
+        if prev < 0:
+            raise ValueError(f"calm_gemm_set_option({option}, {value}) -> {prev}")
+        return prev
+
     def gemm(self, A, B, Cout, M, N, K, a, b, c, batch=(1, 1), alpha=1.0, inv_scale=None, bias=None,
              col_scale=None, residual=None, r=(0, 0, 0), C_pre=None, aux=None, act=ACT_NONE,
              accumulate=False, reduce_batch=False, split_k=0, a_dq=None, b_dq=None):

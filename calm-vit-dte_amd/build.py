@@ -10,7 +10,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcalmvit_hip.so")
-SOURCES = ["gemm.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_bf16p_kk.hip", "gemm_bf16p_km.hip", "gemm_bf16p_mm.hip", "gemm_fp8.hip", "norm_act.hip", "spectral.hip", "tokens_conv.hip", "cnn_fused.hip",
+SOURCES = ["gemm.hip", "gemm_f32.hip", "gemm_bf16.hip", "gemm_bf16p_kk.hip", "gemm_bf16p_km.hip", "gemm_bf16p_mm.hip", "gemm_f32p_kk.hip", "gemm_f32p_km.hip", "gemm_f32p_mm.hip", "gemm_fp8.hip", "norm_act.hip", "spectral.hip", "tokens_conv.hip", "cnn_fused.hip",
            "attention_fused.hip", "attention_bf16.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

@@ -1,6 +1,7 @@
 // calm_gemm: strided / batched / split-K GEMM with fused epilogue for gfx950 — the dispatcher.
 // Two kernel families share tiling, remap, split logic and epilogue (gemm_common.h): the exact fp32 MFMA family
 // (gemm_f32.hip) and the bf16-operand family (gemm_bf16.hip).
+#include <atomic>
 #include "gemm_common.h"
 #include <stdlib.h>
 
@@ -50,38 +51,43 @@ inline bool mult4(int64_t x) { return (x & 3) == 0; }
 // problems.  CALM_GEMM_PIPE=0 in the environment switches the family off (A/B runs).
 constexpr int PIPE_DECLINED = -1000;
 
-static bool pipe_enabled() {
-    static const int on = [] {
-        const char* e = getenv("CALM_GEMM_PIPE");
-        return (e && e[0] == '0') ? 0 : 1;
-    }();
-    return on != 0;
+static std::atomic<int>& pipe_option(int which) {
+    static std::atomic<int> opt[2] = {
+        [] { const char* e = getenv("CALM_GEMM_PIPE"); return (e && e[0] == '0') ? 0 : 1; }(),
+        [] { const char* e = getenv("CALM_GEMM_PIPE32"); return e ? atoi(e) : 0; }()};
+    return opt[which];
 }
+static bool pipe_enabled() { return pipe_option(CALM_GEMM_OPT_PIPE).load(std::memory_order_relaxed) != 0; }
+// fp32 instantiation: 0 off (default), 1 every eligible launch, 2 k-contiguous operand pairs only
+static int pipe32_mode() { return pipe_enabled() ? pipe_option(CALM_GEMM_OPT_PIPE32).load(std::memory_order_relaxed) : 0; }
 
 // modelled duration of a launch (cycles of one CU, up to a common factor): `rounds` items per persistent workgroup, each
 // nk k-tiles of a (64 mt) x (32 nt) tile; a k-tile is bound by its MFMAs (64 mt nt cycles per SIMD at two waves) or by
 // staging its (64 mt + 32 nt) x 128 bytes at ~40 B per cycle; the epilogue costs about one extra k-tile per tile row set
-static double pipe_cost(long items, int mt, int nt, int nk, bool split) {
+// (fp32: eight 32-cycle v_mfma_f32_16x16x4_f32 per tile, k-tile and wave instead of two 16-cycle bf16 ones)
+static double pipe_cost(long items, int mt, int nt, int nk, bool split, bool f32) {
     const long rounds = (items + 255) / 256;
-    const double mfma = 64.0 * mt * nt, stage = (64.0 * mt + 32.0 * nt) * 128.0 / 40.0;
+    const double mfma = (f32 ? 512.0 : 64.0) * mt * nt, stage = (64.0 * mt + 32.0 * nt) * 128.0 / 40.0;
     const double ktile = (mfma > stage ? mfma : stage) + 120.0;
-    const double epi = (split ? 90.0 : 45.0) * mt * nt + 600.0;
+    const double epi = (split ? 90.0 : f32 ? 70.0 : 45.0) * mt * nt + 600.0;
     return rounds * (nk * ktile + epi);
 }
 
-static int pipe_run(const calm_gemm_args* a, GemmP& p, bool akc, bool bkc, hipStream_t s, int64_t* query) {
+static int pipe_run(const calm_gemm_args* a, GemmP& p, bool akc, bool bkc, bool f32, hipStream_t s, int64_t* query) {
     if (!akc && bkc) return PIPE_DECLINED;                      // row-contiguous A with k-contiguous B: not instantiated
     if (a->reduce_batch || !p.epi_vec) return PIPE_DECLINED;
     if ((a->act == CALM_ACT_GELU_BWD) + (a->residual != nullptr) + (a->accumulate != 0) > 1) return PIPE_DECLINED;   // one C-shaped epilogue operand
-    if (a->M < 128 || a->N < 64 || a->K < 64) return PIPE_DECLINED;
+    const int kt = f32 ? 32 : 64;                               // k per k-tile (128 bytes)
+    if (a->M < 128 || a->N < 64 || a->K < kt) return PIPE_DECLINED;
     const int batch = a->batch0 * a->batch1;
     // per-lane staging offsets are 32-bit byte offsets from the batch entry's base
     const int64_t span_a = akc ? (int64_t)a->M * a->a_rs : 64 * a->a_cs + a->M;
     const int64_t span_b = bkc ? (int64_t)a->N * a->b_rs : 64 * a->b_cs + a->N;
-    if (span_a >= (1ll << 30) || span_b >= (1ll << 30)) return PIPE_DECLINED;
+    const int64_t span_max = f32 ? (1ll << 29) : (1ll << 30);
+    if (span_a >= span_max || span_b >= span_max) return PIPE_DECLINED;
     if ((int64_t)a->M * a->c_rs >= (1ll << 29)) return PIPE_DECLINED;        // the epilogue's 32-bit byte offsets into C
     const bool trivial_epi = !a->bias && !a->col_scale && !a->residual && !a->C_pre && a->act == CALM_ACT_NONE;
-    const int kpb = (a->K + 63) / 64;
+    const int kpb = (a->K + kt - 1) / kt;
 
     // k-split: the same decisions as the 256-thread families (weight gradients: one problem, or independent groups,
     // whose tiles alone cannot fill the chip)
@@ -92,18 +98,21 @@ static int pipe_run(const calm_gemm_args* a, GemmP& p, bool akc, bool bkc, hipSt
     if (k_split && !group_split && batch != 1) return PIPE_DECLINED;
     // where the 256-thread kernels measured faster inside the training step (Base-224, same box): narrow k-split outputs,
     // small grouped weight gradients, reductions of two or three k-tiles
-    if (k_split && (a->M < 200 || a->N < 200)) return PIPE_DECLINED;
-    if (group_split && (int64_t)a->M * a->N < 100000) return PIPE_DECLINED;
-    if (!k_split && a->K < 160) return PIPE_DECLINED;
+    if (!f32) {
+        if (k_split && (a->M < 200 || a->N < 200)) return PIPE_DECLINED;
+        if (group_split && (int64_t)a->M * a->N < 100000) return PIPE_DECLINED;
+        if (!k_split && a->K < 160) return PIPE_DECLINED;
+    }
     if (k_split && (!trivial_epi || a->c_type != CALM_ST_F32)) return PIPE_DECLINED;
 
     int best_mt = 0, best_nt = 0, best_split = 1;
     double best = 1e300;
     for (int mt = 2; mt <= 4; ++mt)
         for (int nt = 4; nt <= 8; ++nt) {
+            if (f32 && mt == 4 && nt == 8) continue;            // 128 accumulators + fp32 fragments: spills
             const long tiles = (long)((a->M + 64 * mt - 1) / (64 * mt)) * ((a->N + 32 * nt - 1) / (32 * nt));
             if (!k_split) {
-                const double c = pipe_cost(tiles * batch, mt, nt, kpb, false);
+                const double c = pipe_cost(tiles * batch, mt, nt, kpb, false, f32);
                 if (c < best) { best = c; best_mt = mt; best_nt = nt; best_split = 1; }
                 continue;
             }
@@ -116,7 +125,7 @@ static int pipe_run(const calm_gemm_args* a, GemmP& p, bool akc, bool bkc, hipSt
                 ns = (kpb + nk - 1) / nk;
                 // the slices' partial tiles are combined through atomics / the workspace: M x N x 4 bytes each at ~1 TB/s
                 const double comb = ns > 1 ? (double)a->M * a->N * 4.0 * ns * (group_split ? batch : 1) / 1.0e12 * 2.0e9 / 256.0 : 0.0;
-                const double c = pipe_cost(per * ns, mt, nt, nk, ns > 1) + comb;
+                const double c = pipe_cost(per * ns, mt, nt, nk, ns > 1, f32) + comb;
                 if (c < best) { best = c; best_mt = mt; best_nt = nt; best_split = ns; }
             }
         }
@@ -179,7 +188,11 @@ static int pipe_run(const calm_gemm_args* a, GemmP& p, bool akc, bool bkc, hipSt
         p.epi_unit = u8 ? 8 : 4;
     }
     int rc;
-    if (akc && bkc) rc = launch_pipe_kk(p, mt, nt, grid, s);
+    if (f32) {
+        if (akc && bkc) rc = launch_pipe32_kk(p, mt, nt, grid, s);
+        else if (akc) rc = launch_pipe32_km(p, mt, nt, grid, s);
+        else rc = launch_pipe32_mm(p, mt, nt, grid, s);
+    } else if (akc && bkc) rc = launch_pipe_kk(p, mt, nt, grid, s);
     else if (akc) rc = launch_pipe_km(p, mt, nt, grid, s);
     else rc = launch_pipe_mm(p, mt, nt, grid, s);
     if (rc || !use_ws) return rc;
@@ -290,7 +303,11 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
     if (!vec && any_bf16_tensor) return CALM_E_LAYOUT;
     const int family = vec ? a->dtype : CALM_F32;
     if (family == CALM_BF16 && a->a_type == CALM_ST_BF16 && a->b_type == CALM_ST_BF16 && pipe_enabled()) {
-        const int rc = pipe_run(a, p, akc, bkc, s, query);
+        const int rc = pipe_run(a, p, akc, bkc, false, s, query);
+        if (rc != PIPE_DECLINED) return rc;
+    }
+    if (vec && a->dtype == CALM_F32 && !any_bf16_tensor && (pipe32_mode() == 1 || (pipe32_mode() == 2 && akc && bkc))) {
+        const int rc = pipe_run(a, p, akc, bkc, true, s, query);
         if (rc != PIPE_DECLINED) return rc;
     }
     const int bk = family == CALM_F32 ? BK : CK;
@@ -443,6 +460,12 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
 }
 
 extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) { return gemm_run(a, stream, nullptr); }
+
+extern "C" int calm_gemm_set_option(int32_t option, int32_t value) {
+    if (option != CALM_GEMM_OPT_PIPE && option != CALM_GEMM_OPT_PIPE32) return CALM_E_INVAL;
+    if (value < 0 || value > (option == CALM_GEMM_OPT_PIPE ? 1 : 2)) return CALM_E_INVAL;
+    return pipe_option(option).exchange(value);
+}
 
 extern "C" int64_t calm_gemm_workspace_bytes(const calm_gemm_args* a) {
     int64_t bytes = 0;

@@ -35,7 +35,6 @@ typedef short ps16x4 __attribute__((ext_vector_type(4)));
 typedef short ps16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PTHREADS = 512;
-constexpr int PBK = 64;
 constexpr unsigned PSTAGE = 65536, PB_OFF = 32768;
 
 // 16 zero bytes in device memory (one copy per translation unit: no relocatable device code): source of the LDS-DMA
@@ -82,19 +81,27 @@ __device__ __forceinline__ void glds16_addr(const void* addr, unsigned lds_dst) 
 // 32-byte granules of the 256-byte bank row
 __device__ __forceinline__ int mc_swz(int kk) { return (kk & 3) | (((kk >> 3) & 1) << 2); }
 
-// Staging of one operand: T rows (64 MT or 32 NT) x 64 k per k-tile.
+// Staging of one operand: T rows (64 MT or 32 NT) x 128 bytes of k per k-tile (KT = 64 bf16 or 32 fp32 values; ES =
+// bytes per element).
 //   KC: memory [row][k] (k contiguous).  Image [row][128 B]; instruction q covers rows 8q..8q+7.
-//   MC: memory [k][row] (rows contiguous).  Image [64 k][W B], W = 256 (<= 128 rows) or 512; instruction q covers 1024 / W k-rows.
-template <bool KC, int ROWS>
+//   MC: memory [k][row] (rows contiguous).  Image [KT k][W B], W = 128 ES (<= 128 rows) or 256 ES; instruction q covers
+//       1024 / W k-rows.  Chunk swizzle by k-row: bf16 mc_swz(k) << 1 (transposed reads), fp32 ((k >> 2) & 3) << 2 (the
+//       four lane groups of a ds_read_b32 fragment read — k = 4 g + j, 16 rows x 4 B each — take four different 64-byte
+//       quarters of the 256-byte bank row).
+template <bool KC, int ROWS, int ES>
 struct PStage {
-    static constexpr int W = ROWS <= 128 ? 256 : 512;                 // MC: bytes per k-row
-    static constexpr int TOTAL = KC ? ROWS / 8 : 64 * W / 1024;       // LDS-DMA instructions per k-tile (all waves)
+    static constexpr int KT = 128 / ES;                               // k per k-tile
+    static constexpr int RPC = 16 / ES;                               // rows (MC) or k (KC) per 16-byte chunk
+    static constexpr int W = (ROWS <= 128 ? 128 : 256) * ES;          // MC: bytes per k-row
+    static constexpr int TOTAL = KC ? ROWS / 8 : KT * W / 1024;       // LDS-DMA instructions per k-tile (all waves)
     static constexpr int PER_WAVE = (TOTAL + 7) / 8;
     unsigned off[PER_WAVE];            // per-lane byte offset from the tile's uniform base
     const char* base;                  // uniform: operand base of the batch entry + k offset of the current tile
     long step;                         // bytes per k-tile
 
-    __device__ __forceinline__ void init(const __bf16* origin, long rs, long cs, int row0, int nrows_all, int k0,
+    static __device__ __forceinline__ int mc_chunk_swz(int kk) { return ES == 2 ? (mc_swz(kk) << 1) : (((kk >> 2) & 3) << 2); }
+
+    __device__ __forceinline__ void init(const void* origin, long rs, long cs, int row0, int nrows_all, int k0,
                                          int wave, int lane) {
         if constexpr (KC) {
             const int g = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
@@ -102,27 +109,31 @@ struct PStage {
             for (int i = 0; i < PER_WAVE; ++i) {
                 const int q = wave + 8 * i;
                 const int row = min(row0 + 8 * q + (lane >> 3), nrows_all - 1);
-                off[i] = (unsigned)(row * rs * 2 + g * 16);
+                off[i] = (unsigned)(row * rs * ES + g * 16);
             }
-            base = reinterpret_cast<const char*>(origin) + (long)k0 * 2;
-            step = PBK * 2;
+            base = reinterpret_cast<const char*>(origin) + (long)k0 * ES;
+            step = 128;
         } else {
             constexpr int CPR = W / 16, KPI = 1024 / W;
 #pragma unroll
             for (int i = 0; i < PER_WAVE; ++i) {
                 const int q = wave + 8 * i;
                 const int kk = q * KPI + lane / CPR;
-                const int c = (lane % CPR) ^ (mc_swz(kk) << 1);
-                int row = row0 + 8 * c;
-                if (8 * c >= ROWS || row >= nrows_all) row = row0;          // never used by a live output: any valid address
-                off[i] = (unsigned)(kk * cs * 2 + row * 2);
+                const int c = (lane % CPR) ^ mc_chunk_swz(kk);
+                int row = row0 + RPC * c;
+                if (RPC * c >= ROWS || row >= nrows_all) row = row0;        // never used by a live output: any valid address
+                off[i] = (unsigned)(kk * cs * ES + row * ES);
             }
-            base = reinterpret_cast<const char*>(origin) + (long)k0 * cs * 2;
-            step = PBK * cs * 2;
+            base = reinterpret_cast<const char*>(origin) + (long)k0 * cs * ES;
+            step = KT * cs * ES;
         }
     }
+    // first k (within the k-tile) of this lane's chunk in instruction q — recomputed where needed, not kept across the k-loop
+    static __device__ __forceinline__ int kfirst_of(int q, int wave, int lane) {
+        return KC ? RPC * ((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) : q * (1024 / W) + lane / (W / 16);
+    }
     // piece i (one LDS-DMA instruction of this wave) of the k-tile at `base` into the image at LDS byte `dst`;
-    // k_left < 64: last k-tile of a reduction whose length is not a multiple of 64 — chunks past the end read zeros
+    // k_left < KT: last k-tile of a reduction whose length is not a multiple of KT — chunks past the end read zeros
     template <int I, bool TAIL>
     __device__ __forceinline__ void issue_piece(unsigned dst, int wave, int lane, int k_left, unsigned long long ubase) {
         const int q = wave + 8 * I;
@@ -130,8 +141,7 @@ struct PStage {
         if constexpr (!TAIL) {
             glds16_u(ubase, off[I], dst + 1024u * q);
         } else {
-            const int kfirst = KC ? 8 * ((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) : q * (1024 / W) + lane / (W / 16);
-            const char* a = kfirst < k_left ? base + off[I] : reinterpret_cast<const char*>(calm_zero_block);
+            const char* a = kfirst_of(q, wave, lane) < k_left ? base + off[I] : reinterpret_cast<const char*>(calm_zero_block);
             glds16_addr(a, dst + 1024u * q);
         }
     }
@@ -145,32 +155,36 @@ struct PStage {
         }
         base += step;
     }
-    // last k-tile of a reduction with k_left (< 64) valid k: chunks past the end read zeros
+    // last k-tile of a reduction with k_left (< KT) valid k: chunks past the end read zeros
     __device__ __forceinline__ void issue_tail(unsigned dst, int wave, int lane, int k_left) {
 #pragma unroll
         for (int i = 0; i < PER_WAVE; ++i) {
             const int q = wave + 8 * i;
-            // first k (within the k-tile) this lane's chunk covers — recomputed here, not kept across the k-loop
-            const int kfirst = KC ? 8 * ((lane & 7) ^ (((wave & 1) << 2) | (lane >> 4))) : q * (1024 / W) + lane / (W / 16);
-            const char* a = kfirst < k_left ? base + off[i] : reinterpret_cast<const char*>(calm_zero_block);
+            const char* a = kfirst_of(q, wave, lane) < k_left ? base + off[i] : reinterpret_cast<const char*>(calm_zero_block);
             if (TOTAL % 8 == 0 || q < TOTAL) glds16_addr(a, dst + 1024u * q);
         }
         base += step;
     }
 };
 
-// MFMA operand fragment of the 16 rows starting at tile index `t` (units of 16 rows) for k-step ks (32 k):
-// lane l gets row (l & 15), k = 32 ks + 8 (l >> 4) + 0..7.
-template <bool KC, int ROWS>
+// MFMA operand fragment (16 bytes per lane) of the 16 rows starting at tile index `t` (units of 16 rows) for k-step ks
+// (half a k-tile).  bf16: lane l gets row (l & 15), k = 32 ks + 8 (l >> 4) + 0..7 — one v_mfma_f32_16x16x32_bf16 operand.
+// fp32: row (l & 15), k = 16 ks + 4 (l >> 4) + 0..3 — element j is the operand of the j-th of four
+// v_mfma_f32_16x16x4_f32 (which then multiplies k in {j, 4 + j, 8 + j, 12 + j}: a fixed permutation of the reduction
+// order, the same for A and B).
+template <int ES> struct pfrag_type { typedef pbf16x8 type; };
+template <> struct pfrag_type<4> { typedef f32x4 type; };
+
+template <bool KC, int ROWS, int ES>
 struct PFrag {
-    static constexpr int W = PStage<KC, ROWS>::W;
-    static constexpr int NTILE = ROWS / 16 / (KC ? 1 : 1);
+    typedef typename pfrag_type<ES>::type frag_t;
+    static constexpr int W = PStage<KC, ROWS, ES>::W;
     unsigned rd[KC ? 1 : ROWS / 16];       // KC: one base (tiles by immediate); MC: one per 16-row tile of the WAVE (filled up to n)
     template <int N>
     __device__ __forceinline__ void init(int tile0, int lane) {        // tile0: first 16-row tile of this wave, N tiles
         if constexpr (KC) {
             rd[0] = (unsigned)((tile0 * 16 + (lane & 15)) * 128 + (((lane >> 4) ^ ((lane & 15) >> 1)) << 4));
-        } else {
+        } else if constexpr (ES == 2) {
             const int f = ((lane >> 2) & 3) | (((lane >> 4) & 1) << 2);
             const unsigned bl = (unsigned)((8 * (lane >> 4) + ((lane & 15) >> 2)) * W + 8 * (lane & 1));
 #pragma unroll
@@ -178,22 +192,35 @@ struct PFrag {
                 const int c = 2 * (tile0 + t) + ((lane >> 1) & 1);
                 rd[t] = bl + (unsigned)((c ^ (f << 1)) << 4);
             }
+        } else {
+            const int r = lane & 15, g = lane >> 4;
+#pragma unroll
+            for (int t = 0; t < N; ++t)
+                rd[t] = (unsigned)(4 * g * W + (((4 * (tile0 + t) + (r >> 2)) ^ (g << 2)) << 4) + 4 * (r & 3));
         }
     }
-    __device__ __forceinline__ pbf16x8 load(const char* __restrict__ image, int t, int ks) const {
+    __device__ __forceinline__ frag_t load(const char* __restrict__ image, int t, int ks) const {
         if constexpr (KC) {
             const unsigned a = (rd[0] ^ (ks ? 64u : 0u)) + 2048u * t;
-            return *reinterpret_cast<const pbf16x8*>(image + a);
-        } else {
+            return *reinterpret_cast<const frag_t*>(image + a);
+        } else if constexpr (ES == 2) {
             const char* a0 = image + rd[t] + 32 * ks * W;
             const ps16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4*)(a0));
             const ps16x4 hi4 =
                 __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ps16x4*)(a0 + 4 * W));
             ps16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
             return __builtin_bit_cast(pbf16x8, v);
+        } else {
+            const float* a0 = reinterpret_cast<const float*>(image + rd[t] + 16 * ks * W);
+            return f32x4{a0[0], a0[W / 4], a0[2 * (W / 4)], a0[3 * (W / 4)]};
         }
     }
 };
+
+// one k-step of one 16 x 16 output tile in the swapped orientation (D^T += B A^T)
+__device__ __forceinline__ void pipe_mma(const pbf16x8& b, const pbf16x8& a, f32x4& acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b, a, acc, 0, 0, 0);
+}
 
 // Epilogue of the swapped-operand accumulators: acc[mt][nt][e] = C(row0 + 16 mt + (lane & 15), col0 + 16 nt + 4 (lane >> 4) + e).
 // Same arithmetic as gemm_epilogue (gemm_common.h).
@@ -452,19 +479,21 @@ __device__ __forceinline__ void pipe_epilogue(const GemmP& p, f32x4 (&acc)[MT][N
     }
 }
 
-template <bool AKC, bool BKC, int MT, int NT>
-__global__ __launch_bounds__(PTHREADS, 2) void gemm_bf16p_kernel(const GemmP p) {
+template <typename E, bool AKC, bool BKC, int MT, int NT>
+__device__ __forceinline__ void pipe_body(const GemmP& p) {
     constexpr int BM_ = 64 * MT, BN_ = 32 * NT;
-    typedef PStage<AKC, BM_> StA;
-    typedef PStage<BKC, BN_> StB;
+    constexpr int ES = sizeof(E), PBK = 128 / ES;              // k per k-tile: 64 bf16 / 32 fp32
+    typedef PStage<AKC, BM_, ES> StA;
+    typedef PStage<BKC, BN_, ES> StB;
+    typedef typename pfrag_type<ES>::type frag_t;
     __shared__ __attribute__((aligned(1024))) char lds[2 * PSTAGE + 2048];     // two operand stages + the tile's bias / LayerScale
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    PFrag<AKC, BM_> fa;
-    PFrag<BKC, BN_> fb;
+    PFrag<AKC, BM_, ES> fa;
+    PFrag<BKC, BN_, ES> fb;
     fa.template init<MT>(wm * MT, lane);
     fb.template init<NT>(wn * NT, lane);
 
@@ -502,9 +531,9 @@ __global__ __launch_bounds__(PTHREADS, 2) void gemm_bf16p_kernel(const GemmP p) 
     };
     auto setup = [&](int m0, int n0, int z, int kb0) {
         const int b0 = z / p.batch1, b1 = z - b0 * p.batch1;
-        sa.init(operand_base<__bf16>(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, kb0 * PBK, wave,
+        sa.init(operand_base<E>(p.A, p.Ag, p.n_group, p.a_b0, p.a_b1, b0, b1), p.a_rs, p.a_cs, m0, p.M, kb0 * PBK, wave,
                 lane);
-        sb.init(operand_base<__bf16>(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, kb0 * PBK, wave,
+        sb.init(operand_base<E>(p.B, p.Bg, p.n_group, p.b_b0, p.b_b1, b0, b1), p.b_rs, p.b_cs, n0, p.N, kb0 * PBK, wave,
                 lane);
     };
     // k-tile kb of the item being staged -> stage st
@@ -624,12 +653,12 @@ __global__ __launch_bounds__(PTHREADS, 2) void gemm_bf16p_kernel(const GemmP p) 
 #ifndef CALM_PIPE_DEEP
 #define CALM_PIPE_DEEP 0      // measured on 57344 x 672 x 672: 36.9k vs 37.0k cycles per k-loop, at +40 VGPRs — off
 #endif
-            constexpr bool DEEP = CALM_PIPE_DEEP && MT * NT <= 28;    // registers for two full fragment sets beside the accumulators
+            constexpr bool DEEP = CALM_PIPE_DEEP && ES == 2 && MT * NT <= 28;    // registers for two full fragment sets beside the accumulators
             if constexpr (DEEP) {
                 // k-step 1's fragments (MT + NT reads) are requested while k-step 0's MT NT products issue — a whole
                 // k-step of lookahead (an LDS read under load takes ~300 cycles, an MFMA group NT x 16): one exposed LDS
                 // latency per k-tile, the one right after the barrier
-                pbf16x8 a0[MT], b0[NT], a1[MT], b1[NT];
+                frag_t a0[MT], b0[NT], a1[MT], b1[NT];
 #pragma unroll
                 for (int j = 0; j < NT; ++j) b0[j] = fb.load(ib, j, 0);
 #pragma unroll
@@ -648,7 +677,7 @@ __global__ __launch_bounds__(PTHREADS, 2) void gemm_bf16p_kernel(const GemmP p) 
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0[j], a0[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) pipe_mma(b0[j], a0[i], acc[i][j]);
                     __builtin_amdgcn_sched_barrier(0);
                 };
                 group0(std::integral_constant<int, 0>{});
@@ -658,16 +687,16 @@ __global__ __launch_bounds__(PTHREADS, 2) void gemm_bf16p_kernel(const GemmP p) 
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
 #pragma unroll
-                    for (int j = 0; j < NT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1[j], a1[i], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) pipe_mma(b1[j], a1[i], acc[i][j]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             } else {
             // (one group of lookahead: the A fragment of the next group, and the B fragments of k-step 1 replace those of
             // k-step 0 one by one behind their last use)
-            pbf16x8 bf[NT];
+            frag_t bf[NT];
 #pragma unroll
             for (int j = 0; j < NT; ++j) bf[j] = fb.load(ib, j, 0);
-            pbf16x8 a_cur = fa.load(ia, 0, 0);
+            frag_t a_cur = fa.load(ia, 0, 0);
             auto group = [&](auto kstag, auto itag) __attribute__((always_inline)) {
                 constexpr int ks = decltype(kstag)::value, i = decltype(itag)::value;
 #if CALM_PIPE_PRIO_FLIP
@@ -679,14 +708,28 @@ __global__ __launch_bounds__(PTHREADS, 2) void gemm_bf16p_kernel(const GemmP p) 
                 }
 #endif
                 if constexpr (ks == 0) stage_pieces(std::integral_constant<int, i>{});
-                pbf16x8 a_next = a_cur;
+                frag_t a_next = a_cur;
                 if constexpr (i + 1 < MT) a_next = fa.load(ia, i + 1, ks);
                 else if constexpr (ks == 0) a_next = fa.load(ia, 0, 1);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ES == 2) {
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j], a_cur, acc[i][j], 0, 0, 0);
-                    if constexpr (i == MT - 1 && ks == 0) bf[j] = fb.load(ib, j, 1);
+                    for (int j = 0; j < NT; ++j) {
+                        pipe_mma(bf[j], a_cur, acc[i][j]);
+                        if constexpr (i == MT - 1 && ks == 0) bf[j] = fb.load(ib, j, 1);
+                    }
+                } else {
+                    // four 16x16x4 products per tile and k-step, element by element across the NT tiles: consecutive
+                    // MFMAs never share an accumulator
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[j][e], a_cur[e], acc[i][j], 0, 0, 0);
+                            if constexpr (i == MT - 1 && ks == 0) {
+                                if (e == 3) bf[j] = fb.load(ib, j, 1);
+                            }
+                        }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 a_cur = a_next;
@@ -739,24 +782,42 @@ __global__ __launch_bounds__(PTHREADS, 2) void gemm_bf16p_kernel(const GemmP p) 
     }
 }
 
-template <bool AKC, bool BKC, int MT>
+template <bool AKC, bool BKC, int MT, int NT>
+__global__ __launch_bounds__(PTHREADS, 2) void gemm_bf16p_kernel(const GemmP p) {
+    pipe_body<__bf16, AKC, BKC, MT, NT>(p);
+}
+// the same pipeline on fp32 tensors and v_mfma_f32_16x16x4_f32 (exact fp32 products, fp32 accumulate): k-tiles of 32
+template <bool AKC, bool BKC, int MT, int NT>
+__global__ __launch_bounds__(PTHREADS, 2) void gemm_f32p_kernel(const GemmP p) {
+    pipe_body<float, AKC, BKC, MT, NT>(p);
+}
+
+#define CALM_PIPE_LAUNCH(KERNEL, NTV) \
+    case NTV: hipLaunchKernelGGL((KERNEL<AKC, BKC, MT, NTV>), dim3(grid), dim3(PTHREADS), 0, s, p); break;
+
+template <bool F32, bool AKC, bool BKC, int MT>
 int launch_pipe_nt(const GemmP& p, int nt, int grid, hipStream_t s) {
-    switch (nt) {
-    case 4: hipLaunchKernelGGL((gemm_bf16p_kernel<AKC, BKC, MT, 4>), dim3(grid), dim3(PTHREADS), 0, s, p); break;
-    case 5: hipLaunchKernelGGL((gemm_bf16p_kernel<AKC, BKC, MT, 5>), dim3(grid), dim3(PTHREADS), 0, s, p); break;
-    case 6: hipLaunchKernelGGL((gemm_bf16p_kernel<AKC, BKC, MT, 6>), dim3(grid), dim3(PTHREADS), 0, s, p); break;
-    case 7: hipLaunchKernelGGL((gemm_bf16p_kernel<AKC, BKC, MT, 7>), dim3(grid), dim3(PTHREADS), 0, s, p); break;
-    case 8: hipLaunchKernelGGL((gemm_bf16p_kernel<AKC, BKC, MT, 8>), dim3(grid), dim3(PTHREADS), 0, s, p); break;
-    default: return CALM_E_UNSUPP;
+    if constexpr (F32) {
+        switch (nt) {
+            CALM_PIPE_LAUNCH(gemm_f32p_kernel, 4) CALM_PIPE_LAUNCH(gemm_f32p_kernel, 5) CALM_PIPE_LAUNCH(gemm_f32p_kernel, 6)
+            CALM_PIPE_LAUNCH(gemm_f32p_kernel, 7) CALM_PIPE_LAUNCH(gemm_f32p_kernel, 8)
+        default: return CALM_E_UNSUPP;
+        }
+    } else {
+        switch (nt) {
+            CALM_PIPE_LAUNCH(gemm_bf16p_kernel, 4) CALM_PIPE_LAUNCH(gemm_bf16p_kernel, 5) CALM_PIPE_LAUNCH(gemm_bf16p_kernel, 6)
+            CALM_PIPE_LAUNCH(gemm_bf16p_kernel, 7) CALM_PIPE_LAUNCH(gemm_bf16p_kernel, 8)
+        default: return CALM_E_UNSUPP;
+        }
     }
     CALM_LAUNCH_CHECK();
     return 0;
 }
-template <bool AKC, bool BKC>
+template <bool F32, bool AKC, bool BKC>
 int launch_pipe_layout(const GemmP& p, int mt, int nt, int grid, hipStream_t s) {
-    if (mt == 2) return launch_pipe_nt<AKC, BKC, 2>(p, nt, grid, s);
-    if (mt == 3) return launch_pipe_nt<AKC, BKC, 3>(p, nt, grid, s);
-    if (mt == 4) return launch_pipe_nt<AKC, BKC, 4>(p, nt, grid, s);
+    if (mt == 2) return launch_pipe_nt<F32, AKC, BKC, 2>(p, nt, grid, s);
+    if (mt == 3) return launch_pipe_nt<F32, AKC, BKC, 3>(p, nt, grid, s);
+    if (mt == 4) return launch_pipe_nt<F32, AKC, BKC, 4>(p, nt, grid, s);
     return CALM_E_UNSUPP;
 }
 

@@ -3,6 +3,6 @@
 
 namespace calm_gemm_detail {
 int launch_pipe_km(const GemmP& p, int mt, int nt, int grid, hipStream_t s) {
-    return launch_pipe_layout<true, false>(p, mt, nt, grid, s);
+    return launch_pipe_layout<false, true, false>(p, mt, nt, grid, s);
 }
 }  // namespace calm_gemm_detail

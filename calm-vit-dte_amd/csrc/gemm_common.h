@@ -339,5 +339,9 @@ int launch_fp8(const GemmP& p, dim3 grid, hipStream_t s);           // gemm_fp8.
 int launch_pipe_kk(const GemmP& p, int mt, int nt, int grid, hipStream_t s);
 int launch_pipe_km(const GemmP& p, int mt, int nt, int grid, hipStream_t s);
 int launch_pipe_mm(const GemmP& p, int mt, int nt, int grid, hipStream_t s);
+// the same family on fp32 tensors (gemm_f32p_kernel, v_mfma_f32_16x16x4_f32, k-tiles of 32)
+int launch_pipe32_kk(const GemmP& p, int mt, int nt, int grid, hipStream_t s);
+int launch_pipe32_km(const GemmP& p, int mt, int nt, int grid, hipStream_t s);
+int launch_pipe32_mm(const GemmP& p, int mt, int nt, int grid, hipStream_t s);
 
 }  // namespace calm_gemm_detail

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CALM_ABI_VERSION 5
+#define CALM_ABI_VERSION 6
 
 #define CALM_E_INVAL   (-1)   /* null pointer / negative size                 */
 #define CALM_E_LAYOUT  (-2)   /* stride pattern the kernel cannot address     */
@@ -127,6 +127,17 @@ int calm_gemm(const calm_gemm_args* args, void* stream);
  * Passing less (or NULL) is always valid: the launch then uses atomics.  The caller owns the buffer; it is only used
  * until the launch's kernels have run on `stream`. */
 int64_t calm_gemm_workspace_bytes(const calm_gemm_args* args);
+
+/* ABI v6 — kernel-family switches of calm_gemm (process-wide tuning knobs, not part of the reference's interface: every
+ * setting computes the same products to rounding).  Returns the previous value, CALM_E_INVAL for an unknown option.
+ *   CALM_GEMM_OPT_PIPE    1 (default; env CALM_GEMM_PIPE):  bf16-tensor launches on the pipelined persistent family
+ *   CALM_GEMM_OPT_PIPE32  0 (default; env CALM_GEMM_PIPE32): fp32-tensor launches on the same pipeline
+ *                         (gemm_f32p_kernel) — 1: every eligible launch, 2: k-contiguous operand pairs only.  Off by
+ *                         default: the fp32 matrix pipe is clock-limited under sustained load and both families end
+ *                         at the same rate. */
+#define CALM_GEMM_OPT_PIPE   0
+#define CALM_GEMM_OPT_PIPE32 1
+int calm_gemm_set_option(int32_t option, int32_t value);
 
 /* ---------------------------------------------------------------------------------------
  * LayerNorm(D, eps, bias=False) over the last axis (Vi_Tools:131-132,197,494; fwd 211-215,311,523).

@@ -225,7 +225,7 @@ def test_bench_finds_its_kernels_in_the_committed_pmc_summaries():
     for prefix in list(bench.GEMM_PMC_PREFIX.values()) + list(bench.ATTN_PMC_PREFIX.values()):
         rows, source, stale = bench.pmc_rows(prefix)
         assert rows and source, prefix
-        assert source.startswith("profiles/round2_"), (prefix, source)
+        assert source.startswith("profiles/round3_"), (prefix, source)      # the newest committed round
         assert stale in (True, False)
     for f in glob.glob(os.path.join(root, "profiles", "round2_*pmc_summary.csv")):
         assert os.path.exists(f + ".stamp.json"), f
