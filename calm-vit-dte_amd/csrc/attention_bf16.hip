@@ -22,6 +22,8 @@
 // ds_read_b64_tr_b16 use a stride = 32 (mod 64) bytes — both conflict-free; images read in paired-tile order
 // (ds_read_b64) use a stride = 16 (mod 32) bytes.
 #include "common.h"
+#include "lds_dma.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -56,6 +58,7 @@ struct Attn16P {
     int B, S, H, hd;
     float scale;
     int kv_shared;      // K_h and V_h do not both fit in LDS: one image, V_h staged after the Q K^T products
+    int groups;         // query groups (workgroups) per image — attn16_fwd2_kernel's 1-D grid
 };
 
 constexpr size_t LDS_BUDGET = 80 * 1024;       // two workgroups per CU when a kernel stays below this
@@ -448,8 +451,34 @@ __global__ __launch_bounds__(256) void mask_transpose_kernel(const __bf16* __res
     }
 }
 
+#include "attention_bf16_fwd2.h"
+
+// CALM_ATTN16_V2=0 in the environment: the register-staged forward for every shape (A/B runs)
+inline bool fwd2_enabled() {
+    static const int on = [] { const char* e = getenv("CALM_ATTN16_V2"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+
 template <int NP, int HDP>
 int launch_fwd16_t(const Attn16P& p, size_t lds, hipStream_t s) {
+    if constexpr (Fwd2Geo<NP, HDP>::OK) {
+        if (fwd2_enabled()) {
+            constexpr int lds2 = Fwd2Geo<NP, HDP>::LDS;
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn16_fwd2_kernel<NP, HDP>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+            if (e2 != hipSuccess) return (int)e2;
+            constexpr int nw2 = waves_for(NP);
+            const int tiles2 = (p.S + 15) / 16;
+            Attn16P p2 = p;
+            p2.groups = (tiles2 + nw2 - 1) / nw2;
+            hipLaunchKernelGGL((attn16_fwd2_kernel<NP, HDP>), dim3(p2.groups * p.B), dim3(64 * nw2), lds2, s, p2);
+            CALM_LAUNCH_CHECK();
+            const int t32b = (p.S + 31) / 32;
+            hipLaunchKernelGGL(mask_transpose_kernel, dim3(t32b, t32b, p.B), dim3(256), 0, s, (const __bf16*)p.Mk, p.MkT, p.S);
+            CALM_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn16_fwd_kernel<NP, HDP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -821,7 +850,7 @@ int calm_attention16_fwd(const void* q, const void* k, const void* v, const void
     Attn16P p{(const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)w1, b1, s1, (const __bf16*)w2, b2, s2,
               (__bf16*)out, (__bf16*)R, (__bf16*)hp, (__bf16*)hg, (__bf16*)Mk, (__bf16*)MkT, lse, B, S, H, hd,
               1.0f / sqrtf((float)hd),
-              fwd_kv_shared(S, hd) ? 1 : 0};
+              fwd_kv_shared(S, hd) ? 1 : 0, 0};
     hipStream_t s = as_stream(stream);
     const int nw = pick_waves16(S);
     const size_t lds = fwd_lds_bytes(S, hd);

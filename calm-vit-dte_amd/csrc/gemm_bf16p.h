@@ -23,6 +23,7 @@
 // pipeline.  The k-loop contains no other vector-memory instruction, so the hand-placed vmcnt(0) per k-tile is exact.
 #pragma once
 #include "gemm_common.h"
+#include "lds_dma.h"
 
 #ifndef CALM_PIPE_PRIO_FLIP
 #define CALM_PIPE_PRIO_FLIP 0      // trading priority between the two waves of a SIMD once per k-step: measured +-0 (36.8k vs 36.9k cycles)
@@ -30,52 +31,14 @@
 
 namespace calm_gemm_detail {
 
+using namespace calm_lds_dma;
+
 typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
 typedef short ps16x4 __attribute__((ext_vector_type(4)));
 typedef short ps16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int PTHREADS = 512;
 constexpr unsigned PSTAGE = 65536, PB_OFF = 32768;
-
-// 16 zero bytes in device memory (one copy per translation unit: no relocatable device code): source of the LDS-DMA
-// lanes that fall past K in the last k-tile
-static __device__ __attribute__((aligned(16))) unsigned calm_zero_block[4];
-
-// one LDS-DMA instruction: lane l's 16 bytes at `base + voff` -> LDS byte lds_dst + 16 l (lds_dst wave-uniform)
-__device__ __forceinline__ void glds16(const void* base, unsigned voff, unsigned lds_dst) {
-    unsigned keep;
-    // `base` is wave-uniform by construction; say so (an "s" operand the compiler holds in VGPRs does not assemble)
-    const unsigned long long b64 = reinterpret_cast<unsigned long long>(base);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);           // (the builtin returns int:
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));   //  widen as unsigned)
-    const unsigned long long bu = ((unsigned long long)hi << 32) | lo;
-    lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(bu), "s"(lds_dst) : "memory");
-}
-// wave-uniform 64-bit value as an SGPR pair (an "s" asm operand the compiler holds in VGPRs does not assemble)
-__device__ __forceinline__ unsigned long long pipe_uniform64(const void* p) {
-    const unsigned long long b64 = reinterpret_cast<unsigned long long>(p);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b64);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b64 >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-// lean form for the k-loop: `base` already uniform (pipe_uniform64, once per k-tile), M0 declared clobbered instead
-// of saved and restored — three instructions per piece
-__device__ __forceinline__ void glds16_u(unsigned long long base, unsigned voff, unsigned lds_dst) {
-    lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);
-    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :: "v"(voff), "s"(base), "s"(lds_dst) : "memory", "m0");
-}
-// the same with a full per-lane address (last k-tile of a reduction whose length is not a multiple of 64)
-__device__ __forceinline__ void glds16_addr(const void* addr, unsigned lds_dst) {
-    unsigned keep;
-    lds_dst = (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst);
-    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
-                 "global_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(addr), "s"(lds_dst) : "memory");
-}
 
 // k-row swizzle of the [k][row] images: the 8 k-rows one 32-lane half of a transposed read touches get 8 different
 // 32-byte granules of the 256-byte bank row
@@ -244,13 +207,7 @@ typedef unsigned pu32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned pu32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 pbf16x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t pipe_rsrc(const void* base, long bytes) {
-    const unsigned long long b = reinterpret_cast<unsigned long long>(base);
-    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
-    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
-    const int n = __builtin_amdgcn_readfirstlane((int)(bytes > 0xFFFFFFF0l ? 0xFFFFFFF0l : bytes));
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
-}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pipe_rsrc(const void* base, long bytes) { return make_rsrc(base, bytes); }
 // U consecutive elements (fp32 or bf16 per `type`) at element index i of `base` -> v[0 .. U/4)
 template <int U>
 __device__ __forceinline__ void pipe_load(const char* __restrict__ base, long i, int type, f32x4 (&v)[U / 4]) {

@@ -19,5 +19,7 @@ for B, S, H, hd in [(256, 224, 12, 56), (256, 176, 12, 44), (256, 128, 12, 32), 
     for _ in range(3):
         be.attn16_fwd(q, k, v, w1, b1, s1, w2, b2, s2, out, R, hp, hg, Mk, MkT, lse, B, S, H, hd)
     torch.cuda.synchronize()
-    ph = lse[:, 0, :3].double().mean(0).tolist()
+    ph = lse[:, 0, :12].double().mean(0).tolist()
+    if os.environ.get("CALM_ATTN16_V2", "1") != "0" and S >= 16:
+        print(f"   v2 wave 0: wait+barrier {ph[3]:8.0f} {ph[4]:8.0f} {ph[5]:8.0f} | DMA issue {ph[6]:8.0f} {ph[7]:8.0f} {ph[8]:8.0f} | compute {ph[9]:8.0f} {ph[10]:8.0f} {ph[11]:8.0f}")
     print(f"S{S} hd{hd}: phase1 (R = Q K^T) {ph[0]:9.0f}  phase2 (mask MLP) {ph[1]:9.0f}  phase3 (heads) {ph[2]:9.0f} cycles per workgroup")
