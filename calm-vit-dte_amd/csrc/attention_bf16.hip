@@ -61,6 +61,21 @@ struct Attn16P {
     int groups;         // query groups (workgroups) per image — attn16_fwd2_kernel's 1-D grid
 };
 
+// 1-D grids of (groups x B) workgroups.  Workgroup ids go round-robin over the 8 XCDs; the row groups of ONE image are
+// dealt to the same XCD next to each other in time, so that the second group's K / V / Q / dO requests hit the L2 the
+// first one filled (PMC, round 3: the query-side backward read 1.3 GB per launch at 4.7 TB/s — every image's operands
+// fetched once per group from HBM).  Needs B % 8 == 0; other batches keep the plain order.
+__device__ __forceinline__ void image_and_group(int id, int groups, int B, int& b, int& grp) {
+    if ((B & 7) == 0) {
+        const int xcd = id & 7, idx = id >> 3;                           // idx-th workgroup of this XCD
+        grp = idx % groups;
+        b = (idx / groups) * 8 + xcd;
+    } else {
+        grp = id % groups;
+        b = id / groups;
+    }
+}
+
 constexpr size_t LDS_BUDGET = 80 * 1024;       // two workgroups per CU when a kernel stays below this
 
 // stride (in bf16 elements) of a [row][cols] image that is read by 16-byte fragments and by transposed reads
@@ -151,9 +166,10 @@ __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void at
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g = lane >> 4;
-    const int b = blockIdx.y;
+    int b, qg;
+    image_and_group(blockIdx.x, p.groups, p.B, b, qg);
     const int S = p.S, D = p.H * p.hd, hd = p.hd;
-    const int q_lane = blockIdx.x * (16 * NW) + 16 * wave + c16;                    // this lane's query
+    const int q_lane = qg * (16 * NW) + 16 * wave + c16;                            // this lane's query
     const bool q_ok = q_lane < S;
     const int q_ld = q_ok ? q_lane : S - 1;                                         // clamped: loads stay in range
     const __bf16* qrow = p.q + ((long)b * S + q_ld) * D;
@@ -422,7 +438,7 @@ __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void at
     }
 #ifdef ATT16_STAMP
     __syncthreads();
-    if (tid == 0 && blockIdx.x == 0) {       // diagnostic build only: phase cycles over the lse of the first queries of head 0
+    if (tid == 0 && qg == 0) {       // diagnostic build only: phase cycles over the lse of the first queries of head 0
         const unsigned long long ts3 = __builtin_amdgcn_s_memtime();
         float* d = p.lse + (long)b * p.H * S;
         d[0] = (float)(ts1 - ts0); d[1] = (float)(ts2 - ts1); d[2] = (float)(ts3 - ts2);
@@ -484,8 +500,9 @@ int launch_fwd16_t(const Attn16P& p, size_t lds, hipStream_t s) {
     if (e != hipSuccess) return (int)e;
     constexpr int nw = waves_for(NP);
     const int tiles = (p.S + 15) / 16;
-    dim3 grid((tiles + nw - 1) / nw, p.B);
-    hipLaunchKernelGGL((attn16_fwd_kernel<NP, HDP>), grid, dim3(64 * nw), lds, s, p);
+    Attn16P p1 = p;
+    p1.groups = (tiles + nw - 1) / nw;
+    hipLaunchKernelGGL((attn16_fwd_kernel<NP, HDP>), dim3(p1.groups * p.B), dim3(64 * nw), lds, s, p1);
     CALM_LAUNCH_CHECK();
     const int t32 = (p.S + 31) / 32;
     hipLaunchKernelGGL(mask_transpose_kernel, dim3(t32, t32, p.B), dim3(256), 0, s, (const __bf16*)p.Mk, p.MkT, p.S);
@@ -542,6 +559,7 @@ struct Attn16BP {
     int B, S, H, hd;
     float scale;
     int ch;             // tile pairs per LDS chunk
+    int groups;         // row groups (workgroups) per image
 };
 
 // tile pairs whose two images fit the LDS budget of a workgroup (two workgroups per CU)
@@ -567,9 +585,10 @@ __global__ __launch_bounds__(64 * waves_for(NP)) void attn16_bwd_q_kernel(const 
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3;
-    const int b = blockIdx.y;
+    int b, qg;
+    image_and_group(blockIdx.x, p.groups, p.B, b, qg);
     const int S = p.S, D = p.H * p.hd, hd = p.hd;
-    const int q_lane = blockIdx.x * (16 * (blockDim.x >> 6)) + 16 * wave + c16;
+    const int q_lane = qg * (16 * (blockDim.x >> 6)) + 16 * wave + c16;
     const bool q_ok = q_lane < S;
     const int q_ld = q_ok ? q_lane : S - 1;
     const long qoff = ((long)b * S + q_ld) * D;
@@ -690,9 +709,10 @@ __global__ __launch_bounds__(64 * waves_for(NP)) void attn16_bwd_kv_kernel(const
     extern __shared__ __attribute__((aligned(16))) __bf16 smem16[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c16 = lane & 15, g = lane >> 4, q4 = c16 >> 2, p4 = c16 & 3;
-    const int b = blockIdx.y;
+    int b, kg;
+    image_and_group(blockIdx.x, p.groups, p.B, b, kg);
     const int S = p.S, D = p.H * p.hd, hd = p.hd;
-    const int k_lane = blockIdx.x * (16 * (blockDim.x >> 6)) + 16 * wave + c16;       // this lane's key
+    const int k_lane = kg * (16 * (blockDim.x >> 6)) + 16 * wave + c16;               // this lane's key
     const bool k_ok = k_lane < S;
     const int k_ld = k_ok ? k_lane : S - 1;
     const long koff = ((long)b * S + k_ld) * D;
@@ -810,10 +830,12 @@ int launch_bwd16_t(const Attn16BP& p, int nw, hipStream_t s) {
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     const int tiles = (p.S + 15) / 16;
-    dim3 grid((tiles + nw - 1) / nw, p.B);
-    hipLaunchKernelGGL((attn16_bwd_q_kernel<NP, HDP>), grid, dim3(64 * nw), lds, s, p);
+    Attn16BP p1 = p;
+    p1.groups = (tiles + nw - 1) / nw;
+    const dim3 grid(p1.groups * p.B);
+    hipLaunchKernelGGL((attn16_bwd_q_kernel<NP, HDP>), grid, dim3(64 * nw), lds, s, p1);
     CALM_LAUNCH_CHECK();
-    hipLaunchKernelGGL((attn16_bwd_kv_kernel<NP, HDP>), grid, dim3(64 * nw), lds, s, p);
+    hipLaunchKernelGGL((attn16_bwd_kv_kernel<NP, HDP>), grid, dim3(64 * nw), lds, s, p1);
     CALM_LAUNCH_CHECK();
     return 0;
 }
@@ -846,7 +868,7 @@ int calm_attention16_fwd(const void* q, const void* k, const void* v, const void
         B <= 0)
         return CALM_E_INVAL;
     if (!calm_attention16_supported(S, H, hd)) return CALM_E_UNSUPP;
-    if (B > 65535) return CALM_E_UNSUPP;
+    if (B > 65535) return CALM_E_UNSUPP;                    // mask_transpose_kernel's grid.z
     Attn16P p{(const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)w1, b1, s1, (const __bf16*)w2, b2, s2,
               (__bf16*)out, (__bf16*)R, (__bf16*)hp, (__bf16*)hg, (__bf16*)Mk, (__bf16*)MkT, lse, B, S, H, hd,
               1.0f / sqrtf((float)hd),
@@ -877,10 +899,10 @@ int calm_attention16_bwd(const void* q, const void* k, const void* v, const void
     if (!q || !k || !v || !out || !dout || !Mk || !MkT || !lse || !delta || !dq || !dk || !dv || !dM || B <= 0)
         return CALM_E_INVAL;
     if (!calm_attention16_supported(S, H, hd)) return CALM_E_UNSUPP;
-    if (B > 65535) return CALM_E_UNSUPP;
+
     Attn16BP p{(const __bf16*)q, (const __bf16*)k, (const __bf16*)v, (const __bf16*)out, (const __bf16*)dout,
                (const __bf16*)Mk, (const __bf16*)MkT, lse, delta, (__bf16*)dq, (__bf16*)dk, (__bf16*)dv, (__bf16*)dM,
-               B, S, H, hd, 1.0f / sqrtf((float)hd), bwd_chunk_pairs(S, hd)};
+               B, S, H, hd, 1.0f / sqrtf((float)hd), bwd_chunk_pairs(S, hd), 0};
     hipStream_t s = as_stream(stream);
     const int nw = pick_waves16(S);
     switch ((S + 31) / 32) {
