@@ -820,8 +820,36 @@ __global__ __launch_bounds__(64 * waves_for(NP)) void attn16_bwd_kv_kernel(const
 
 inline int bwd_chunk_pairs(int S, int hd) { return bwd_chunk_pairs_c((S + 31) / 32, (hd + 31) / 32 * 32); }
 
+#include "attention_bf16_bwd2.h"
+
+// CALM_ATTN16_BWD2=0 in the environment: the register-staged backward kernels for every shape (A/B runs)
+inline bool bwd2_enabled() {
+    static const int on = [] { const char* e = getenv("CALM_ATTN16_BWD2"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+
 template <int NP, int HDP>
 int launch_bwd16_t(const Attn16BP& p, int nw, hipStream_t s) {
+    if constexpr (Bwd2Geo<NP, HDP, false>::OK && Bwd2Geo<NP, HDP, true>::OK) {
+        if (bwd2_enabled()) {
+            Attn16BP p2 = p;
+            const int tiles2 = (p.S + 15) / 16;
+            p2.groups = (tiles2 + nw - 1) / nw;
+            const dim3 grid2(p2.groups * p.B);
+            constexpr int ldq = Bwd2Geo<NP, HDP, false>::LDS, ldk = Bwd2Geo<NP, HDP, true>::LDS;
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn16_bwd2_kernel<NP, HDP, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, ldq);
+            if (e2 != hipSuccess) return (int)e2;
+            e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn16_bwd2_kernel<NP, HDP, true>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, ldk);
+            if (e2 != hipSuccess) return (int)e2;
+            hipLaunchKernelGGL((attn16_bwd2_kernel<NP, HDP, false>), grid2, dim3(64 * nw), ldq, s, p2);
+            CALM_LAUNCH_CHECK();
+            hipLaunchKernelGGL((attn16_bwd2_kernel<NP, HDP, true>), grid2, dim3(64 * nw), ldk, s, p2);
+            CALM_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const size_t lds = (size_t)2 * 32 * p.ch * ld_rt(HDP) * sizeof(__bf16);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn16_bwd_q_kernel<NP, HDP>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
