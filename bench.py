@@ -52,7 +52,8 @@ PEAK_BF16_DENSE_TFLOPS = 2500.0
 PRECISION_INFO = {
     "fp32": ("f32", PEAK_FP32_MATRIX_TFLOPS, "gemm_f32_kernel (calm_gemm, v_mfma_f32_32x32x2_f32)"),
     "bf16": ("bf16 (bf16 GEMM / attention tensors, f32 accumulate, f32 residual stream and parameters)",
-             PEAK_BF16_DENSE_TFLOPS, "gemm_bf16w_kernel / gemm_bf16c_kernel (calm_gemm, v_mfma_f32_32x32x16_bf16)"),
+             PEAK_BF16_DENSE_TFLOPS, "gemm_bf16p_kernel (pipelined persistent family, v_mfma_f32_16x16x32_bf16) + gemm_bf16w / gemm_bf16c_kernel "
+             "(calm_gemm)"),
     "fp8": ("bf16 + fp8 (e4m3 / e5m2 operands of the Linear forward and input-gradient GEMMs, f32 accumulate; bf16 "
             "pipeline elsewhere)", PEAK_BF16_DENSE_TFLOPS,
             "gemm_fp8w_kernel + gemm_bf16w/c_kernel (calm_gemm; non-scaled fp8 MFMAs run at the bf16 rate)"),
@@ -174,7 +175,7 @@ class AttentionProfiler:
 # kernel-name prefixes of the GEMM families in the rocprofv3 summaries (tests/test_host_logic_cpu.py checks that the
 # committed summaries still have rows under them: a renamed kernel or namespace silently turned `traffic` into null)
 GEMM_PMC_PREFIX = {"fp32": "calm_gemm_detail::gemm_f32", "bf16": "calm_gemm_detail::gemm_bf16"}
-ATTN_PMC_PREFIX = {"fp32": "attn_fwd_kernel", "bf16": "attn16_fwd_kernel"}
+ATTN_PMC_PREFIX = {"fp32": "attn_fwd_kernel", "bf16": "attn16_fwd"}       # attn16_fwd2_kernel (pipelined) and attn16_fwd_kernel
 
 
 def pmc_rows(kernel_prefix):
@@ -447,8 +448,8 @@ def main():
                 a = aprof.summary()
                 if a is not None:
                     name, aS, aH, ahd = a["largest"]
-                    kname = "attn16_fwd_kernel" if name == "attn16_fwd" else "attn_fwd_kernel"
-                    rows, source, stale = pmc_rows(kname)
+                    kname = "attn16_fwd2_kernel / attn16_fwd_kernel" if name == "attn16_fwd" else "attn_fwd_kernel"
+                    rows, source, stale = pmc_rows(ATTN_PMC_PREFIX["bf16" if name == "attn16_fwd" else "fp32"])
                     best = max(rows, key=lambda r: float(r["gui_active_sum"])) if rows and not stale else None
                     res["attention"] = {
                         "kernel": f"{kname} (fused latent-mask attention forward, "
