@@ -1,7 +1,7 @@
 #!/bin/bash
 # the other BASELINE configs on one GPU (record only; the bench default stays configs[1])
 R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R; mkdir -p gpurun_out
-run() { timeout -k 10 500 python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --prof-steps 1 "$@" 2>&1 | tail -1 | python3 -c "
+run() { timeout -k 10 500 python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-secondary --prof-steps 1 "$@" 2>&1 | tail -1 | python3 -c "
 import sys, json
 try:
     d = json.loads(sys.stdin.read())

@@ -108,3 +108,47 @@ def test_attention16_backward_matches_emulation(S, H, hd):
     o.transpose(1, 2).reshape(B, S, H * hd).backward(dout.float())
     for n, a, ref in (("dq", dq_h, qf.grad), ("dk", dk_h, kf.grad), ("dv", dv_h, vf.grad)):
         assert rel_err(a.float(), ref) < 4e-2, (n, rel_err(a.float(), ref))
+
+
+@pytest.mark.parametrize("S,H,hd", [(176, 12, 44), (80, 12, 20), (128, 12, 32)])
+def test_attention16_eight_images_take_the_xcd_paired_order(S, H, hd):
+    """B % 8 == 0 switches the attn16 kernels to the XCD-paired workgroup order (image = 8 (idx / groups) + id % 8), and
+    with hd % 8 == 4 the last image's last head stages its last row through the zero block + the by-hand half chunk:
+    forward and backward at B = 8 against the emulation, and image by image against the B = 3 order (a batch is a set of
+    independent images: the same image must give the same bits whichever order its workgroups ran in)."""
+    hip, emu = calm.backend.get_backend(), EmulatedBackend()
+    B = 8
+    ins = _inputs(B, S, H, hd, seed=3)
+    q, k, v, w1, b1, s1, w2, b2, s2 = ins
+    ref = list(_outputs(B, S, H, hd, "cpu"))
+    got = list(_outputs(B, S, H, hd, "cuda"))
+    ref.insert(5, torch.empty_like(ref[4]))
+    got.insert(5, torch.full_like(got[4], float("nan")))
+    emu.attn16_fwd(*ins, *ref, B, S, H, hd)
+    hip.attn16_fwd(*[t.cuda() for t in ins], *got, B, S, H, hd)
+    for n, a, b_ in zip(["out", "R", "hp", "hg", "Mk", "MkT", "lse"], got, ref):
+        assert torch.isfinite(a.float()).all(), n
+        tol = 8e-3 if n == "lse" else 3e-2 if n == "out" else 1.2e-2 if n in ("Mk", "MkT") else 6e-3
+        assert rel_err(a.float(), b_.float()) < tol, (n, rel_err(a.float(), b_.float()))
+    # the last three images alone (B = 3: plain order, and image 2 is then the tensor-end image as well)
+    sub = [t[5:].contiguous().cuda() if t.dim() == 3 and t.shape[0] == B else t.cuda() for t in ins]
+    got3 = list(_outputs(3, S, H, hd, "cuda"))
+    got3.insert(5, torch.full_like(got3[4], float("nan")))
+    hip.attn16_fwd(*sub, *got3, 3, S, H, hd)
+    for a8, a3 in zip(got, got3):
+        assert torch.equal(a8[5:], a3)
+    # backward on the emulation's saved tensors
+    out, R, hp, hg, Mk, MkT, lse = ref
+    dout = torch.randn(B, S, H * hd, generator=torch.Generator().manual_seed(9)).bfloat16()
+    mk = lambda dev: [torch.full((B, S, H * hd), float("nan"), dtype=torch.bfloat16, device=dev) for _ in range(3)] + \
+        [torch.full((B, S, S), float("nan"), dtype=torch.bfloat16, device=dev)]
+    dq_r, dk_r, dv_r, dM_r = mk("cpu")
+    dq_h, dk_h, dv_h, dM_h = mk("cuda")
+    delta_r, delta_h = torch.zeros(B, H, S), torch.full((B, H, S), float("nan"), device="cuda")
+    emu.attn16_bwd(q, k, v, out, dout, Mk, MkT, lse, delta_r, dq_r, dk_r, dv_r, dM_r, B, S, H, hd)
+    c = lambda t: t.cuda()
+    hip.attn16_bwd(c(q), c(k), c(v), c(out), c(dout), c(Mk), c(MkT), c(lse), delta_h, dq_h, dk_h, dv_h, dM_h, B, S, H, hd)
+    assert rel_err(delta_h, delta_r) < 1e-4
+    for n, a, b_ in (("dq", dq_h, dq_r), ("dk", dk_h, dk_r), ("dv", dv_h, dv_r), ("dM", dM_h, dM_r)):
+        assert torch.isfinite(a.float()).all(), n
+        assert rel_err(a.float(), b_.float()) < 1.2e-2, (n, rel_err(a.float(), b_.float()))
