@@ -135,8 +135,8 @@ class AttentionProfiler:
     PV 4 S^2 D)."""
 
     def __init__(self, be):
-        self.be, self.records = be, []
-        self.orig = {n: getattr(be, n) for n in ("attn_fwd", "attn16_fwd")}
+        self.be, self.records, self.bwd = be, [], []
+        self.orig = {n: getattr(be, n) for n in ("attn_fwd", "attn16_fwd", "attn16_bwd")}
 
     def __enter__(self):
         def wrap(name, dims):
@@ -152,6 +152,16 @@ class AttentionProfiler:
             return timed
         self.be.attn_fwd = wrap("attn_fwd", lambda a: (a[15], a[16], a[18], a[19]))          # (..., B, Sq, Skv, H, hd)
         self.be.attn16_fwd = wrap("attn16_fwd", lambda a: (a[16], a[17], a[18], a[19]))      # (..., B, S, H, hd)
+        bwd_fn = self.orig["attn16_bwd"]
+
+        def timed_bwd(*a):                     # the flash-style bf16 backward pair: 14 S^2 D FLOP per image (7 products, two recomputed)
+            B, S, H, hd = a[13], a[14], a[15], a[16]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            bwd_fn(*a)
+            e1.record()
+            self.bwd.append((float(B) * 14.0 * S * S * H * hd, e0, e1, (S, H, hd)))
+        self.be.attn16_bwd = timed_bwd
         return self
 
     def __exit__(self, *exc):
@@ -167,9 +177,16 @@ class AttentionProfiler:
         ms = sum(r[1].elapsed_time(r[2]) for r in self.records)
         big = max(self.records, key=lambda r: r[0])
         same = [r for r in self.records if r[3] == big[3]]
-        return {"flops": flops, "ms": ms, "n": len(self.records), "largest": big[3],
-                "largest_us": 1e3 * sum(r[1].elapsed_time(r[2]) for r in same) / len(same),
-                "largest_tflops": big[0] / (1e-3 * sum(r[1].elapsed_time(r[2]) for r in same) / len(same)) / 1e12}
+        out = {"flops": flops, "ms": ms, "n": len(self.records), "largest": big[3],
+               "largest_us": 1e3 * sum(r[1].elapsed_time(r[2]) for r in same) / len(same),
+               "largest_tflops": big[0] / (1e-3 * sum(r[1].elapsed_time(r[2]) for r in same) / len(same)) / 1e12}
+        if self.bwd:
+            bb = max(self.bwd, key=lambda r: r[0])
+            sb = [r for r in self.bwd if r[3] == bb[3]]
+            us = 1e3 * sum(r[1].elapsed_time(r[2]) for r in sb) / len(sb)
+            out["bwd"] = {"ms": sum(r[1].elapsed_time(r[2]) for r in self.bwd), "n": len(self.bwd), "largest": bb[3],
+                          "largest_us": us, "largest_tflops": bb[0] / (us * 1e-6) / 1e12}
+        return out
 
 
 # kernel-name prefixes of the GEMM families in the rocprofv3 summaries (tests/test_host_logic_cpu.py checks that the
@@ -450,7 +467,10 @@ def main():
                     name, aS, aH, ahd = a["largest"]
                     kname = "attn16_fwd2_kernel / attn16_fwd_kernel" if name == "attn16_fwd" else "attn_fwd_kernel"
                     rows, source, stale = pmc_rows(ATTN_PMC_PREFIX["bf16" if name == "attn16_fwd" else "fp32"])
-                    best = max(rows, key=lambda r: float(r["gui_active_sum"])) if rows and not stale else None
+                    # the instantiation of the largest shape (attn16: <key-tile pairs NP, padded head dim>), else the busiest row
+                    tag = f"<{(aS + 31) // 32}, {(ahd + 31) // 32 * 32}" if name == "attn16_fwd" else None
+                    cand = [r for r in rows if tag and tag in r["kernel"]] or rows
+                    best = max(cand, key=lambda r: float(r["gui_active_sum"])) if rows and not stale else None
                     res["attention"] = {
                         "kernel": f"{kname} (fused latent-mask attention forward, "
                                   f"{'v_mfma_f32_16x16x32_bf16' if name == 'attn16_fwd' else 'v_mfma_f32_16x16x4_f32'})",
@@ -463,6 +483,14 @@ def main():
                         "mfma_util_pmc": round(float(best["mfma_util"]), 4) if best else None,
                         "hbm_GBps_pmc": round(float(best["hbm_GBps"]), 1) if best else None,
                         "pmc_kernel": best["kernel"] if best else None, "pmc_source": source, "pmc_stale": stale}
+                    if "bwd" in a:             # the backward pair of the same kernel family (bf16 pipeline), live timing
+                        bw = a["bwd"]
+                        res["attention"]["backward"] = {
+                            "kernel": "attn16_bwd2_kernel query side + key side / attn16_bwd_q_kernel + attn16_bwd_kv_kernel",
+                            "launches_per_step": bw["n"] // prof_steps, "ms_per_step": round(bw["ms"] / prof_steps, 3),
+                            "largest_shape": {"S": bw["largest"][0], "H": bw["largest"][1], "hd": bw["largest"][2],
+                                              "avg_launch_us": round(bw["largest_us"], 1),
+                                              "tflops": round(bw["largest_tflops"], 2)}}
         if world > 1:
             dist.barrier()
         res["hbm_peak_gib"] = round(torch.cuda.max_memory_allocated(device) / 2**30, 1)
