@@ -180,3 +180,38 @@ def test_small224_bench_config_forward_backward_vs_oracle_and_properties():
         y0, _ = m(x[:1])
     assert torch.equal(ya, yb)
     assert rel_err(ya[:1], y0) < 1e-5
+
+
+def test_small224_bench_config_batch_of_eight_vs_oracle():
+    """The bench model at a batch of 8 — every image's gradient contribution summed in the weight gradients, batched
+    per-image products with batch > 2 — forward, KL, dL/dx and every parameter gradient against the CPU oracle on the same
+    inputs, noise and warmed-up spectral-norm vectors (full-model parity beyond bs = 2 was property-based
+    only)."""
+    cfg, m, params = _small224("cuda")
+    m.train()
+    B = 8
+    x = torch.from_numpy(W.make_input((B, 3, 224, 224), 5)).cuda()
+    for i in range(3):
+        with torch.no_grad():
+            m(x[:2])
+    P = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    for k in P:
+        if not O.is_buffer(k):
+            P[k].requires_grad_(True)
+    xg = x.clone().requires_grad_(True)
+    calm.ops.set_noise_override(W.NoiseStream(17))
+    try:
+        y, kl = m(xg)
+        gy = torch.from_numpy(W.make_input(tuple(y.shape), 6, "gy")).cuda()
+        ((y * gy).sum() + 0.5 * kl).backward()
+    finally:
+        calm.ops.set_noise_override(None)
+    xo = x.cpu().clone().requires_grad_(True)
+    yo, klo = O.vit_forward(P, cfg, xo, True, W.NoiseStream(17))
+    ((yo * gy.cpu()).sum() + 0.5 * klo).backward()
+    assert y.shape == (B, 1000)
+    assert rel_err(y.detach(), yo.detach()) < TOL
+    assert abs(float(kl) - float(klo)) < TOL * max(1.0, abs(float(klo)))
+    assert rel_err(xg.grad, xo.grad) < TOL
+    worst = max((rel_err(p.grad, P[n].grad), n) for n, p in m.named_parameters())
+    assert worst[0] < 5 * TOL, worst
