@@ -384,6 +384,13 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
         nsplit = a->split_k > 1 ? a->split_k : split_slots / tiles;
         const int max_split = (p.kb_total + 7) / 8;
         if (nsplit > max_split) nsplit = max_split;
+        // every slice adds its whole tile onto the SAME output with atomics: beyond about one workgroup per CU the
+        // contention costs more than the shorter slices save (scripts/ab_reduce_split.py, 256 images: 80x176x528 51.6 us
+        // at 512 slices, 33.4 at 128; 224x176x528 69.7 -> 56.5; 128x80x240 24.4 -> 19.7)
+        if (a->split_k <= 1) {
+            const int cap = tiles == 1 ? 128 : 256 / tiles;
+            if (nsplit > cap) nsplit = cap;
+        }
         if (nsplit < 1) nsplit = 1;
     } else if (k_split) {
         if (batch != 1) return CALM_E_UNSUPP;
