@@ -123,8 +123,10 @@ static int pipe_run(const calm_gemm_args* a, GemmP& p, bool akc, bool bkc, bool 
                 if (ns > kpb / 4) ns = kpb / 4 > 0 ? kpb / 4 : 1;
                 const int nk = (kpb + ns - 1) / ns;
                 ns = (kpb + nk - 1) / nk;
-                // the slices' partial tiles are combined through atomics / the workspace: M x N x 4 bytes each at ~1 TB/s
-                const double comb = ns > 1 ? (double)a->M * a->N * 4.0 * ns * (group_split ? batch : 1) / 1.0e12 * 2.0e9 / 256.0 : 0.0;
+                // the slices' partial tiles are combined through atomics / the workspace: M x N x 4 bytes each through a
+                // CHIP-WIDE resource at ~2 TB/s (scripts/ab_wgrad_split.py: 240 x 480 x 20480 takes 23.9 us with 16 slices,
+                // 31.3 with 64, 38.3 with 128 — 0.13 us per 460 KB slice), in cycles of the launch like pipe_cost
+                const double comb = ns > 1 ? (double)a->M * a->N * 4.0 * ns * (group_split ? batch : 1) / 2.0e12 * 2.0e9 : 0.0;
                 const double c = pipe_cost(per * ns, mt, nt, nk, ns > 1, f32) + comb;
                 if (c < best) { best = c; best_mt = mt; best_nt = nt; best_split = ns; }
             }
@@ -397,6 +399,9 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
         nsplit = a->split_k > 1 ? a->split_k : split_slots / tiles;
         const int max_split = (p.kpb + 15) / 16;
         if (nsplit > max_split) nsplit = max_split;
+        // small outputs (the 128-row kernels' share of the weight gradients): every slice adds its tiles onto the same
+        // output — about one workgroup per CU is the optimum (264 x 240 x 45056: 41.9 us at 88 slices, 29.7 at 32)
+        if (a->split_k <= 1 && !wide && nsplit > 256 / tiles) nsplit = 256 / tiles;
         if (nsplit < 1) nsplit = 1;
         p.kb_total = p.kpb;
         p.atomic = nsplit > 1;
