@@ -389,7 +389,8 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
         // every slice adds its whole tile onto the SAME output with atomics: beyond about one workgroup per CU the
         // contention costs more than the shorter slices save (scripts/ab_reduce_split.py, 256 images: 80x176x528 51.6 us
         // at 512 slices, 33.4 at 128; 224x176x528 69.7 -> 56.5; 128x80x240 24.4 -> 19.7)
-        if (a->split_k <= 1) {
+        // (measured on the bf16-operand kernels; the fp32 kernels, 16x slower per k-block, keep their full round of slices)
+        if (a->split_k <= 1 && family == CALM_BF16) {
             const int cap = tiles == 1 ? 128 : 256 / tiles;
             if (nsplit > cap) nsplit = cap;
         }
@@ -401,7 +402,8 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
         if (nsplit > max_split) nsplit = max_split;
         // small outputs (the 128-row kernels' share of the weight gradients): every slice adds its tiles onto the same
         // output — about one workgroup per CU is the optimum (264 x 240 x 45056: 41.9 us at 88 slices, 29.7 at 32)
-        if (a->split_k <= 1 && !wide && nsplit > 256 / tiles) nsplit = 256 / tiles;
+        // (bf16-operand kernels only: as above)
+        if (a->split_k <= 1 && family == CALM_BF16 && !wide && nsplit > 256 / tiles) nsplit = 256 / tiles;
         if (nsplit < 1) nsplit = 1;
         p.kb_total = p.kpb;
         p.atomic = nsplit > 1;
