@@ -83,12 +83,14 @@ def _ptr16(t):
     return t.data_ptr()
 
 
+_ST_OF = {torch.bfloat16: _lib.ST_BF16, torch.float8_e4m3fn: _lib.ST_FP8_E4M3, torch.float8_e5m2: _lib.ST_FP8_E5M2}
+
+
 def _st(t):
     """CALM_ST_* storage type of a tensor argument (None -> fp32)."""
     if t is None:
         return _lib.ST_F32
-    return {torch.bfloat16: _lib.ST_BF16, torch.float8_e4m3fn: _lib.ST_FP8_E4M3,
-            torch.float8_e5m2: _lib.ST_FP8_E5M2}.get(t.dtype, _lib.ST_F32)
+    return _ST_OF.get(t.dtype, _lib.ST_F32)
 
 
 def bf16_pipeline():
