@@ -110,7 +110,8 @@ def test_attention16_backward_matches_emulation(S, H, hd):
         assert rel_err(a.float(), ref) < 4e-2, (n, rel_err(a.float(), ref))
 
 
-@pytest.mark.parametrize("S,H,hd", [(176, 12, 44), (80, 12, 20), (128, 12, 32)])
+@pytest.mark.parametrize("S,H,hd", [(176, 12, 44), (80, 12, 20), (128, 12, 32),            # pipelined kernels (Base-224 stages)
+                                    (224, 6, 112), (200, 6, 100), (288, 12, 72)])          # register-staged kernels (hd > 64)
 def test_attention16_eight_images_take_the_xcd_paired_order(S, H, hd):
     """B % 8 == 0 switches the attn16 kernels to the XCD-paired workgroup order (image = 8 (idx / groups) + id % 8), and
     with hd % 8 == 4 the last image's last head stages its last row through the zero block + the by-hand half chunk:
