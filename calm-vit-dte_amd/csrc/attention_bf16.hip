@@ -640,9 +640,18 @@ __global__ __launch_bounds__(64 * waves_for(NP)) void attn16_bwd_q_kernel(const 
         f32x4v dqa[MAXDT];
 #pragma unroll
         for (int dt = 0; dt < MAXDT; ++dt) dqa[dt] = (f32x4v){0.f, 0.f, 0.f, 0.f};
+        // the mask of a pair is requested one pair ahead (round 3: it used to be loaded and waited for inside the pair —
+        // one exposed memory round trip per head and key pair)
+        auto mask_of = [&](int pr) __attribute__((always_inline)) {
+            const int j0 = 32 * pr + 4 * g, j1 = j0 + 16;             // pad keys: mask -inf -> P = 0
+            return cat8(j0 < S ? ld4(Mrow + j0) : ninf, j1 < S ? ld4(Mrow + j1) : ninf);
+        };
+        bf16x8 mf_next = mask_of(0);
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) {
             __builtin_amdgcn_sched_barrier(0);             // one pair at a time: no hoisting of the next pair's reads
+            const bf16x8 mf = mf_next;
+            if (pr + 1 < NP) mf_next = mask_of(pr + 1);
             const int lp = pr % p.ch;                      // uniform
             if (lp == 0) {
                 __syncthreads();
@@ -669,8 +678,6 @@ __global__ __launch_bounds__(64 * waves_for(NP)) void attn16_bwd_q_kernel(const 
                     d1 = MFMA_BF16(*reinterpret_cast<const bf16x8*>(imgV + o1), dof[ks], d1);
                 }
             }
-            const int j0 = 32 * pr + 4 * g, j1 = j0 + 16;                // pad keys: mask -inf -> P = 0
-            const bf16x8 mf = cat8(j0 < S ? ld4(Mrow + j0) : ninf, j1 < S ? ld4(Mrow + j1) : ninf);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float pa = __expf(fmaf(s0[r], p.scale, (float)mf[r]) - lse);
@@ -750,9 +757,26 @@ __global__ __launch_bounds__(64 * waves_for(NP)) void attn16_bwd_kv_kernel(const
         f32x4v dva[MAXDT], dka[MAXDT];
 #pragma unroll
         for (int dt = 0; dt < MAXDT; ++dt) { dva[dt] = (f32x4v){0.f, 0.f, 0.f, 0.f}; dka[dt] = dva[dt]; }
+        // mask column, lse and delta of a query pair are requested one pair ahead (round 3: were loaded and waited for
+        // inside the pair)
+        struct PairIn { bf16x8 mf; f32x4v l0, l1, e0, e1; };
+        auto pair_in = [&](int pr) __attribute__((always_inline)) {
+            const int i0 = 32 * pr + 4 * g, i1 = i0 + 16;
+            const f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
+            PairIn o;
+            o.l0 = i0 < S ? *reinterpret_cast<const f32x4v*>(lse_h + i0) : z4;
+            o.l1 = i1 < S ? *reinterpret_cast<const f32x4v*>(lse_h + i1) : z4;
+            o.e0 = i0 < S ? *reinterpret_cast<const f32x4v*>(del_h + i0) : z4;
+            o.e1 = i1 < S ? *reinterpret_cast<const f32x4v*>(del_h + i1) : z4;
+            o.mf = cat8(i0 < S ? ld4(Mcol + i0) : zero4, i1 < S ? ld4(Mcol + i1) : zero4);
+            return o;
+        };
+        PairIn nxt = pair_in(0);
 #pragma unroll
         for (int pr = 0; pr < NP; ++pr) {
             __builtin_amdgcn_sched_barrier(0);
+            const PairIn cur = nxt;
+            if (pr + 1 < NP) nxt = pair_in(pr + 1);
             const int lp = pr % p.ch;
             if (lp == 0) {
                 __syncthreads();
@@ -780,13 +804,8 @@ __global__ __launch_bounds__(64 * waves_for(NP)) void attn16_bwd_kv_kernel(const
                 }
             }
             // queries 32 pr + 4 g + r (tile 0) and + 16 (tile 1); pad queries: Q / dO rows are zero -> no contribution
-            const int i0 = 32 * pr + 4 * g, i1 = i0 + 16;
-            const f32x4v z4 = {0.f, 0.f, 0.f, 0.f};
-            const f32x4v l0 = i0 < S ? *reinterpret_cast<const f32x4v*>(lse_h + i0) : z4;
-            const f32x4v l1 = i1 < S ? *reinterpret_cast<const f32x4v*>(lse_h + i1) : z4;
-            const f32x4v e0 = i0 < S ? *reinterpret_cast<const f32x4v*>(del_h + i0) : z4;
-            const f32x4v e1 = i1 < S ? *reinterpret_cast<const f32x4v*>(del_h + i1) : z4;
-            const bf16x8 mf = cat8(i0 < S ? ld4(Mcol + i0) : zero4, i1 < S ? ld4(Mcol + i1) : zero4);
+            const f32x4v l0 = cur.l0, l1 = cur.l1, e0 = cur.e0, e1 = cur.e1;
+            const bf16x8 mf = cur.mf;
             f32x4v pa, pb;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
