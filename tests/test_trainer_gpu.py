@@ -125,7 +125,9 @@ def test_checkpoint_round_trip(tmp_path):
     m2 = m2.cuda().eval()
     with torch.no_grad():
         y1, kl1 = m2(x.cuda())
-    assert torch.equal(y0, y1) and float(kl0) == float(kl1)
+    # the logits repeat bit for bit; the KL sum is combined over blocks with fp32 atomics (calm_latent_fwd), whose order
+    # — hence last bit — is not fixed (it feeds no weight: its gradient does not depend on its value)
+    assert torch.equal(y0, y1) and abs(float(kl0) - float(kl1)) <= 2e-6 * abs(float(kl0))
 
 
 def _one_step(name, fused, steps=2):
