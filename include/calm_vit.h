@@ -225,6 +225,11 @@ int calm_attention_bwd(const float* q, const float* k, const float* v, const flo
  *   calm_attention16_bwd: dq, dk, dv (bf16, written), dM [B,S,S] (bf16, written; the caller's mask-MLP backward
  *   continues from it); delta [B,H,S] fp32 scratch (rowsum(dO o O) = rowsum(P o dP), written by the query-side
  *   pass, read by the key-side pass); out = the forward's output.
+ * Two kernel generations sit behind these entry points, chosen by shape (same arithmetic, same rounding points):
+ * S <= 224 with hd <= 64 (every stage of Base-224) runs the LDS-DMA pipelined kernels of round 3
+ * (csrc/attention_bf16_fwd2.h, csrc/attention_bf16_bwd2.h), everything else the register-staged ones.  No entry point
+ * uses atomics: results repeat bit for bit.  With B % 8 == 0 the workgroups of one image are dealt to one XCD (L2 reuse
+ * of its K / V); any B is valid.
  * ------------------------------------------------------------------------------------- */
 int calm_attention16_supported(int32_t S, int32_t H, int32_t hd);
 int calm_attention16_fwd(const void* q, const void* k, const void* v, const void* w1, const float* b1, const float* s1,
@@ -237,7 +242,8 @@ int calm_attention16_bwd(const void* q, const void* k, const void* v, const void
 /* ---------------------------------------------------------------------------------------
  * Latent bottleneck sampling (Vi_Tools:232-242) + KL partial sum (Vi_Tools:24-25).
  * mv: [rows, 2*mvh] (mean | raw).  std = softplus(raw)+1e-6;  z = mean + noise*std (noise NULL
- * in eval: z = mean).  kl_sum (device scalar, caller zeroes) += sum(1 + 2 log std - mean^2 - std^2).
+ * in eval: z = mean).  kl_sum (device scalar, caller zeroes) += sum(1 + 2 log std - mean^2 - std^2) — block partials
+ * combined with fp32 atomics: the last bit of kl_sum is not reproducible between runs (z and std are).
  * bwd: dmv from dz and the scalar d(kl_sum) (device pointer).
  * ------------------------------------------------------------------------------------- */
 int calm_latent_fwd(const float* mv, const float* noise, float* z, float* std_out, float* kl_sum,
