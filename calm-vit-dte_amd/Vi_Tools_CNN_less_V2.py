@@ -130,11 +130,12 @@ class RoPE(torch.nn.Module):
 
 
 class GELU(torch.nn.Module):
-    """Index placeholder inside the Sequential containers (keeps `mlp.0/mlp.3`, `linear_mask.0/.2`,
-    `proj.0/.2/.4`, `head.0/.2` key numbering); the activation itself is a GEMM epilogue."""
+    """nn.GELU(approximate='none') of the Sequential containers (keeps `mlp.0/mlp.3`, `linear_mask.0/.2`,
+    `proj.0/.2/.4`, `head.0/.2` key numbering).  On the path the activation is a GEMM epilogue (or lives inside the fused
+    CNN tail) and this module is never called; called on its own it runs the stand-alone erf-GELU kernel."""
 
     def forward(self, x):
-        raise NotImplementedError("GELU is fused into the preceding GEMM; call the parent module")
+        return ops.GeluFn.apply(x)
 
 
 class VMLA_Block(torch.nn.Module):
@@ -332,15 +333,19 @@ class CnnResidual(torch.nn.Sequential):
             SNConv2d(hidden_channels, 3, kernel_size=1, bias=True),
         )
 
-    def residual_forward(self, tokens):
+    def residual_forward(self, tokens, residual=True):
         """tokens [B,S,3S] -> tokens + proj(tokens as [B,3,S,S] image), back in token layout."""
         c0, c2, c4 = self[0], self[2], self[4]
         return ops.CnnResidualFn.apply(tokens, c0.weight_orig, c0.bias, c2.weight_orig, c2.bias, c4.weight_orig,
                                        c4.bias, c0.weight_u, c0.weight_v, c0.sigma(), c2.weight_u, c2.weight_v,
-                                       c2.sigma(), c4.weight_u, c4.weight_v, c4.sigma())
+                                       c2.sigma(), c4.weight_u, c4.weight_v, c4.sigma(), residual)
 
     def forward(self, x):
-        raise NotImplementedError("use residual_forward(tokens): the CNN tail runs fused on the token grid")
+        """`proj(img)` as the reference's Sequential computes it (Vi_Tools:378-385): img [B,3,S,S] -> [B,3,S,S], no skip
+        connection — the same fused kernel with its residual term switched off, between two index-only layout changes."""
+        with sn_scope(self):
+            y = self.residual_forward(ops.image_to_rows(x), residual=False)
+            return ops.RowsToImageFn.apply(y)
 
 
 class Block(torch.nn.Module):
@@ -379,8 +384,10 @@ class Block(torch.nn.Module):
     def forward(self, x, esm=None, dsm=None, csm=None, mask=True):
         with sn_scope(self):
             xq = x
-            if self.is_first_block:
+            if self.is_first_block and x.dim() == 4:
                 xq = ops.image_to_rows(xq)                               # 389-391
+            # (a 3-d input to the first block IS the row-token tensor [B,S,3S]: what trainer.DeviceCollate(tokens=True)
+            # emits straight from the uint8 batch — SURVEY 8f-3 "feeding K1 directly")
             xq = self.encoder(xq, state_manager=esm, mask=mask)
             xkv = ops.grid_transpose(xq)                                 # 394-395
             xkv = self.decoder(xkv, state_manager=dsm, mask=mask)

@@ -14,7 +14,7 @@ ACT_NONE, ACT_GELU, ACT_GELU_BWD = 0, 1, 2
 F32 = 0
 ST_F32, ST_BF16, ST_FP8_E4M3, ST_FP8_E5M2 = 0, 1, 2, 3   # storage type of a tensor in HBM (CALM_ST_*)
 E_INVAL, E_LAYOUT, E_UNSUPP = -1, -2, -3      # CALM_E_*
-ABI_VERSION = 6          # CALM_ABI_VERSION of include/calm_vit.h
+ABI_VERSION = 7          # CALM_ABI_VERSION of include/calm_vit.h
 
 _p = C.c_void_p
 _i32 = C.c_int32
@@ -42,6 +42,15 @@ class GemmArgs(C.Structure):
         ("a_type", _i32), ("b_type", _i32), ("c_type", _i32), ("aux_type", _i32), ("r_type", _i32), ("reserved_", _i32),
         ("a_dq", _p), ("b_dq", _p),
     ]
+
+
+class GemmPlan(C.Structure):
+    """struct calm_gemm_plan (calm_gemm_describe, ABI v7)."""
+    _fields_ = [(n, _i32) for n in ("family", "tile_m", "tile_n", "tile_k", "tiles_m", "tiles_n", "k_slices", "items",
+                                    "grid", "epi_unit", "uses_workspace", "threads")]
+
+
+RED_LAYERNORM_BWD, RED_ROPE_BWD, RED_LATENT_FWD, RED_COLSUM, RED_CNN_BWD = range(5)     # CALM_RED_*
 
 
 class OptimTensor(C.Structure):
@@ -79,15 +88,18 @@ SIGNATURES = {
     "calm_gemm": (_i32, [C.POINTER(GemmArgs), _p]),
     "calm_gemm_workspace_bytes": (_i64, [C.POINTER(GemmArgs)]),
     "calm_gemm_set_option": (C.c_int, [_i32, _i32]),
+    "calm_gemm_describe": (_i32, [C.POINTER(GemmArgs), C.POINTER(GemmPlan)]),
+    "calm_reduce_scratch_floats": (_i64, [_i32, _i64, _i32]),
     "calm_layernorm_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _f32, _i32, _p]),
-    "calm_layernorm_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p]),
+    "calm_layernorm_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _p, _p]),
     "calm_cast_chunk_elems": (_i32, []),
     "calm_cast_bf16": (_i32, [_p, _p, _i32, _p]),
     "calm_cast_bf16_one": (_i32, [_p, _p, _i64, _p]),
+    "calm_cast_f32_one": (_i32, [_p, _p, _i64, _p]),
     "calm_quantize_fp8": (_i32, [_p, _i32, _i64, _p, _i32, _p, _p]),
     "calm_transpose_u8": (_i32, [_p, _p, _i32, _i32, _p]),
     "calm_rope_fwd": (_i32, [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
-    "calm_rope_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p]),
+    "calm_rope_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p, _p]),
     "calm_softmax_fwd": (_i32, [_p, _i64, _i32, _p]),
     "calm_softmax_bwd": (_i32, [_p, _p, _i64, _i32, _p]),
     "calm_softmax_bwd_heads": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _p]),
@@ -99,13 +111,13 @@ SIGNATURES = {
     "calm_attention16_supported": (_i32, [_i32, _i32, _i32]),
     "calm_attention16_fwd": (_i32, [_p] * 16 + [_i32] * 4 + [_p]),
     "calm_attention16_bwd": (_i32, [_p] * 13 + [_i32] * 4 + [_p]),
-    "calm_latent_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _p]),
+    "calm_latent_fwd": (_i32, [_p, _p, _p, _p, _p, _i64, _i32, _p, _p]),
     "calm_latent_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _i64, _i32, _p]),
     "calm_sn_plan": (_i32, [C.POINTER(SnLayer), _i32, _p, C.POINTER(SnPlanInfo)]),
     "calm_sn_power_iter": (_i32, [_p, C.POINTER(SnPlanInfo), _i32, _f32, _p, _p]),
     "calm_sn_weight_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _p, _p]),
     "calm_optim_chunk_elems": (_i32, []),
-    "calm_optim_step": (_i32, [_p, _i32, _p, _i32, _p, C.POINTER(OptimHparams), _p, _p, _p, _p]),
+    "calm_optim_step": (_i32, [_p, _i32, _p, _i32, _p, C.POINTER(OptimHparams), _p, _p, _p, _p, _p]),
     "calm_collate_mix": (_i32, [_p, _p, _p, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p]),
     "calm_collate_crop_mix": (_i32, [_p, _i32, _i32, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _f32, _p, _p, _p, _p]),
     "calm_image_to_rows": (_i32, [_p, _p, _i32, _i32, _p]),
@@ -113,11 +125,12 @@ SIGNATURES = {
     "calm_grid_transpose": (_i32, [_p, _p, _i32, _i32, _p]),
     "calm_dwconv3x3_fwd": (_i32, [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _p]),
     "calm_dwconv3x3_bwd": (_i32, [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _p]),
-    "calm_cnn_residual_fwd": (_i32, [_p] * 11 + [_i32, _i32, _i32, _p]),
-    "calm_cnn_residual_bwd": (_i32, [_p] * 18 + [_i32, _i32, _i32, _p]),
+    "calm_cnn_residual_fwd": (_i32, [_p] * 11 + [_i32, _i32, _i32, _i32, _p]),
+    "calm_cnn_residual_bwd": (_i32, [_p] * 18 + [_i32, _i32, _i32, _i32, _p, _p]),
     "calm_add": (_i32, [_p, _p, _p, _i64, _p]),
+    "calm_gelu_fwd": (_i32, [_p, _p, _i64, _p]),
     "calm_gelu_bwd": (_i32, [_p, _p, _p, _i64, _p]),
-    "calm_colsum": (_i32, [_p, _p, _i64, _i32, _i32, _p]),
+    "calm_colsum": (_i32, [_p, _p, _i64, _i32, _i32, _p, _p]),
     "calm_row_scale": (_i32, [_p, _p, _p, _i32, _i32, _i32, _p]),
     "calm_mean_seq_fwd": (_i32, [_p, _p, _i32, _i32, _i32, _p]),
     "calm_mean_seq_bwd": (_i32, [_p, _p, _i32, _i32, _i32, _p]),

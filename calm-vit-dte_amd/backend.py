@@ -205,21 +205,67 @@ class HipBackend:
 
     def __init__(self):
         self.lib = _lib.load()
+        self._scratch_bufs = {}
+        self.upcast_launches = 0        # calm_gemm launches re-run on fp32 copies (CALM_E_LAYOUT with bf16 tensors)
+
+    def _partials(self, op, rows, cols, device):
+        """Device scratch for the fixed-order cross-workgroup reduction of one call (calm_reduce_scratch_floats).  One
+        buffer per (device, stream), reused by every call on that stream: the launches of one stream run in order, so a
+        call's rows of partials have been consumed by its own reduction pass before the next call writes any."""
+        need = int(self.lib.calm_reduce_scratch_floats(op, rows, cols))
+        key = (device.index, _stream())
+        buf = self._scratch_bufs.get(key)
+        if buf is None or buf.numel() < need:
+            buf = torch.empty(max(need, 1 << 20), dtype=torch.float32, device=device)
+            self._scratch_bufs[key] = buf
+        return buf.data_ptr()
 
     # ---- GEMM -------------------------------------------------------------------------
-    GEMM_OPT_PIPE, GEMM_OPT_PIPE32 = 0, 1
+    GEMM_OPT_PIPE, GEMM_OPT_PIPE32, GEMM_OPT_DETERMINISTIC = 0, 1, 2
 
     def gemm_set_option(self, option, value):
-        """calm_gemm_set_option (ABI v6): kernel-family switches of calm_gemm; returns the previous value."""
+        """calm_gemm_set_option (ABI v6; v7: GEMM_OPT_DETERMINISTIC = k-split launches through the workspace and a
+        fixed-order reduction instead of fp32 atomics); returns the previous value."""
         prev = self.lib.calm_gemm_set_option(int(option), int(value))
         if prev < 0:
             raise ValueError(f"calm_gemm_set_option({option}, {value}) -> {prev}")
         return prev
 
+    def gemm_describe(self, *args, **kw):
+        """calm_gemm_describe (ABI v7) for the launch `gemm(*args, **kw)` would make: a dict of the plan's fields
+        (family, tile, tiles, k-slices, items, grid ...).  Nothing is enqueued."""
+        g, _keep = self._gemm_args(*args, **kw)
+        plan = _lib.GemmPlan()
+        _lib.check(self.lib.calm_gemm_describe(C.byref(g), C.byref(plan)), "calm_gemm_describe")
+        return {name: getattr(plan, name) for name, _ in _lib.GemmPlan._fields_}
+
     def gemm(self, A, B, Cout, M, N, K, a, b, c, batch=(1, 1), alpha=1.0, inv_scale=None, bias=None,
              col_scale=None, residual=None, r=(0, 0, 0), C_pre=None, aux=None, act=ACT_NONE,
              accumulate=False, reduce_batch=False, split_k=0, a_dq=None, b_dq=None):
         """a_dq / b_dq: device dequantisation factors of fp8 operands (quantize_fp8's state[1:2])."""
+        g, (A, B, Cout) = self._gemm_args(A, B, Cout, M, N, K, a, b, c, batch, alpha, inv_scale, bias, col_scale, residual,
+                                          r, C_pre, aux, act, accumulate, reduce_batch, split_k, a_dq, b_dq)
+        ws = None
+        if split_k != 1 and GEMM_WORKSPACE:
+            # split launches with many k-slices per output combine them through a workspace instead of atomics; the
+            # buffer comes from torch's caching allocator and is stream-ordered like every other tensor of the step
+            need = self.lib.calm_gemm_workspace_bytes(C.byref(g))
+            if need > 0:
+                ws = torch.empty(need // 4, dtype=torch.float32, device=Cout.device)
+                g.workspace, g.workspace_bytes = ws.data_ptr(), need
+        rc = self.lib.calm_gemm(C.byref(g), _stream())
+        fp8_operand = g.a_type >= _lib.ST_FP8_E4M3 or g.b_type >= _lib.ST_FP8_E4M3     # fp8 tensors have no fp32 re-run: report
+        if rc == _lib.E_LAYOUT and not fp8_operand and (g.a_type or g.b_type or g.c_type or g.aux_type or g.r_type):
+            # a bf16 tensor in a launch whose sizes / strides rule out 16-byte staging (the 10-class head of the fixture
+            # models, a 36-token stage): rare and tiny — run it on fp32 copies through the generic kernels
+            return self._gemm_upcast(A, B, Cout, M, N, K, a, b, c, batch, alpha, inv_scale, bias, col_scale, residual,
+                                     r, C_pre, aux, act, accumulate, reduce_batch, split_k, g)
+        _lib.check(rc, "calm_gemm")
+
+    def _gemm_args(self, A, B, Cout, M, N, K, a, b, c, batch=(1, 1), alpha=1.0, inv_scale=None, bias=None,
+                   col_scale=None, residual=None, r=(0, 0, 0), C_pre=None, aux=None, act=ACT_NONE,
+                   accumulate=False, reduce_batch=False, split_k=0, a_dq=None, b_dq=None):
+        """(calm_gemm_args, (A, B, C) base tensors) for a launch."""
         g = _lib.GemmArgs()
         # grouped form: A / B / Cout / inv_scale given as lists of separately allocated tensors, one per b0 entry
         groups = [len(t) for t in (A, B, Cout, inv_scale) if isinstance(t, (list, tuple))]
@@ -260,42 +306,31 @@ class HipBackend:
         g.reduce_batch = int(reduce_batch)
         g.split_k = split_k
         g.dtype = PRECISIONS[effective_precision()]
-        ws = None
-        if split_k != 1 and GEMM_WORKSPACE:
-            # split launches with many k-slices per output combine them through a workspace instead of atomics; the
-            # buffer comes from torch's caching allocator and is stream-ordered like every other tensor of the step
-            need = self.lib.calm_gemm_workspace_bytes(C.byref(g))
-            if need > 0:
-                ws = torch.empty(need // 4, dtype=torch.float32, device=Cout.device)
-                g.workspace, g.workspace_bytes = ws.data_ptr(), need
-        rc = self.lib.calm_gemm(C.byref(g), _stream())
-        fp8_operand = g.a_type >= _lib.ST_FP8_E4M3 or g.b_type >= _lib.ST_FP8_E4M3     # fp8 tensors have no fp32 re-run: report
-        if rc == _lib.E_LAYOUT and not fp8_operand and (g.a_type or g.b_type or g.c_type or g.aux_type or g.r_type):
-            # a bf16 tensor in a launch whose sizes / strides rule out 16-byte staging (the 10-class head of the fixture
-            # models, a 36-token stage): rare and tiny — run it on fp32 copies through the generic kernels
-            return self._gemm_upcast(A, B, Cout, M, N, K, a, b, c, batch, alpha, inv_scale, bias, col_scale, residual,
-                                     r, C_pre, aux, act, accumulate, reduce_batch, split_k, g)
-        _lib.check(rc, "calm_gemm")
+        return g, (A, B, Cout)
 
     def _gemm_upcast(self, A, B, Cout, M, N, K, a, b, c, batch, alpha, inv_scale, bias, col_scale, residual, r, C_pre,
                      aux, act, accumulate, reduce_batch, split_k, g):
         if g.n_group:
             raise RuntimeError("calm_gemm: grouped launch with bf16 tensors that cannot be staged (CALM_E_LAYOUT)")
 
+        self.upcast_launches += 1
+
         def up(t):
             if t is None or t.dtype != torch.bfloat16:
                 return t
             if not t.is_contiguous():
                 raise RuntimeError("calm_gemm: non-contiguous bf16 tensor in a launch that cannot be vectorised")
-            return t.float()
+            t32 = torch.empty(t.shape, dtype=torch.float32, device=t.device)
+            _lib.check(self.lib.calm_cast_f32_one(t.data_ptr(), t32.data_ptr(), t.numel(), _stream()), "calm_cast_f32_one")
+            return t32
         C32, P32 = up(Cout), up(C_pre)
         self.gemm(up(A), up(B), C32, M, N, K, a, b, c, batch=batch, alpha=alpha, inv_scale=inv_scale, bias=bias,
                   col_scale=col_scale, residual=up(residual), r=r, C_pre=P32, aux=up(aux), act=act, accumulate=accumulate,
                   reduce_batch=reduce_batch, split_k=split_k)
         if C32 is not Cout:
-            Cout.copy_(C32)
+            self.cast_bf16(C32, Cout)
         if P32 is not C_pre:
-            C_pre.copy_(P32)
+            self.cast_bf16(P32, C_pre)
 
     # ---- device-side collate -------------------------------------------------------------
     def collate_mix(self, img_u8, flip, out, mode, lam, box, mean, std):
@@ -333,14 +368,15 @@ class HipBackend:
         """records: one dict per parameter — param, exp_avg, exp_avg_sq, sn (None or (u, v, sigma, rows, cols))."""
         return OptimPlan(self, records)
 
-    def optim_step(self, plan, grads, hp, grad_scale, stats_out):
+    def optim_step(self, plan, grads, hp, grad_scale, stats_out, lr_dev=None):
         """hp = (lr, beta1, beta2, eps, weight_decay, max_norm, step); stats_out[2] <- grad norm, found_inf.
-        The step count used for the bias correction is plan.step_dev (device; not advanced on skipped steps)."""
+        The step count used for the bias correction is plan.step_dev (device; not advanced on skipped steps).
+        lr_dev: device scalar that overrides hp's lr (a captured step reads its learning rate from it)."""
         plan.upload(np.asarray([_ptr(g) for g in grads], dtype=np.uint64))
         h = _lib.OptimHparams(*hp)
         _lib.check(self.lib.calm_optim_step(plan.table_dev.data_ptr(), plan.n, plan.chunk_dev.data_ptr(), plan.n_chunks,
                                             _ptr(plan.scratch), C.byref(h), _ptr(grad_scale, True), _ptr(stats_out),
-                                            plan.step_dev.data_ptr(), _stream()), "calm_optim_step")
+                                            plan.step_dev.data_ptr(), _ptr(lr_dev, True), _stream()), "calm_optim_step")
 
     # ---- LayerNorm --------------------------------------------------------------------
     def layernorm_fwd(self, x, w, y, mean, rstd, rows, D, eps):
@@ -350,7 +386,8 @@ class HipBackend:
 
     def layernorm_bwd(self, dy, x, w, mean, rstd, dx, dw, rows, D, dx_add=None):
         _lib.check(self.lib.calm_layernorm_bwd(_ptr(dy, bf16_ok=True), _ptr(x), _ptr(w), _ptr(mean), _ptr(rstd), _ptr(dx),
-                                               _ptr(dw), _ptr(dx_add, True), rows, D, _st(dy), _stream()),
+                                               _ptr(dw), _ptr(dx_add, True), rows, D, _st(dy),
+                                               self._partials(_lib.RED_LAYERNORM_BWD, rows, D, x.device), _stream()),
                    "calm_layernorm_bwd")
 
     # ---- bf16 weight copies --------------------------------------------------------------
@@ -409,7 +446,8 @@ class HipBackend:
     def rope_bwd(self, d_out, xr, table, d_content, d_xr, d_inv_freq, B, S, H, dc, dr):
         _lib.check(self.lib.calm_rope_bwd(_ptr(d_out, bf16_ok=True), _ptr(xr, bf16_ok=True), _ptr(table),
                                           _ptr(d_content, True, bf16_ok=True), _ptr(d_xr, bf16_ok=True), _ptr(d_inv_freq),
-                                          B, S, H, dc, dr, _st(d_out), _st(xr), _st(d_content), _st(d_xr), _stream()),
+                                          B, S, H, dc, dr, _st(d_out), _st(xr), _st(d_content), _st(d_xr),
+                                          self._partials(_lib.RED_ROPE_BWD, B * S * H, dr, xr.device), _stream()),
                    "calm_rope_bwd")
 
     # ---- softmax ----------------------------------------------------------------------
@@ -462,7 +500,8 @@ class HipBackend:
     # ---- latent -----------------------------------------------------------------------
     def latent_fwd(self, mv, noise, z, std, kl_sum, rows, mvh):
         _lib.check(self.lib.calm_latent_fwd(_ptr(mv), _ptr(noise, True), _ptr(z), _ptr(std), _ptr(kl_sum), rows,
-                                            mvh, _stream()), "calm_latent_fwd")
+                                            mvh, self._partials(_lib.RED_LATENT_FWD, rows, mvh, mv.device), _stream()),
+                   "calm_latent_fwd")
 
     def latent_bwd(self, dz, d_kl_sum, mv, noise, std, dmv, rows, mvh):
         _lib.check(self.lib.calm_latent_bwd(_ptr(dz, True), _ptr(d_kl_sum, True), _ptr(mv), _ptr(noise, True),
@@ -516,26 +555,34 @@ class HipBackend:
         _lib.check(self.lib.calm_dwconv3x3_bwd(_ptr(dz), _ptr(x), _ptr(w), _ptr(inv_scale, True), _ptr(dx),
                                                _ptr(dw), _ptr(db), B, S, Cch, _stream()), "calm_dwconv3x3_bwd")
 
-    def cnn_fwd(self, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, out, B, S, hidden):
+    def cnn_fwd(self, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, out, B, S, hidden, residual=True):
+        """residual=False: the bare proj(x) (a caller of the reference invoking `block.proj` on its own)."""
         _lib.check(self.lib.calm_cnn_residual_fwd(_ptr(x), _ptr(w0), _ptr(s0), _ptr(b0), _ptr(w2), _ptr(s2),
                                                   _ptr(b2), _ptr(w4), _ptr(s4), _ptr(b4), _ptr(out), B, S, hidden,
-                                                  _stream()), "calm_cnn_residual_fwd")
+                                                  int(residual), _stream()), "calm_cnn_residual_fwd")
 
-    def cnn_bwd(self, dy, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, dx, g0, gb0, g2, gb2, g4, gb4, B, S, hidden):
+    def cnn_bwd(self, dy, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, dx, g0, gb0, g2, gb2, g4, gb4, B, S, hidden,
+                residual=True):
         _lib.check(self.lib.calm_cnn_residual_bwd(_ptr(dy), _ptr(x), _ptr(w0), _ptr(s0), _ptr(b0), _ptr(w2),
                                                   _ptr(s2), _ptr(b2), _ptr(w4), _ptr(s4), _ptr(b4), _ptr(dx),
                                                   _ptr(g0), _ptr(gb0), _ptr(g2), _ptr(gb2), _ptr(g4), _ptr(gb4),
-                                                  B, S, hidden, _stream()), "calm_cnn_residual_bwd")
+                                                  B, S, hidden, int(residual),
+                                                  self._partials(_lib.RED_CNN_BWD, B, S, dy.device), _stream()),
+                   "calm_cnn_residual_bwd")
 
     # ---- helpers ----------------------------------------------------------------------
     def add(self, a, b, out, n):
         _lib.check(self.lib.calm_add(_ptr(a), _ptr(b), _ptr(out), n, _stream()), "calm_add")
 
+    def gelu_fwd(self, x, y, n):
+        _lib.check(self.lib.calm_gelu_fwd(_ptr(x), _ptr(y), n, _stream()), "calm_gelu_fwd")
+
     def gelu_bwd(self, dy, z, dz, n):
         _lib.check(self.lib.calm_gelu_bwd(_ptr(dy), _ptr(z), _ptr(dz), n, _stream()), "calm_gelu_bwd")
 
     def colsum(self, x, out, rows, cols):
-        _lib.check(self.lib.calm_colsum(_ptr(x, bf16_ok=True), _ptr(out), rows, cols, _st(x), _stream()), "calm_colsum")
+        _lib.check(self.lib.calm_colsum(_ptr(x, bf16_ok=True), _ptr(out), rows, cols, _st(x),
+                                        self._partials(_lib.RED_COLSUM, rows, cols, x.device), _stream()), "calm_colsum")
 
     def row_scale(self, x, s, out, rows, cols):
         _lib.check(self.lib.calm_row_scale(_ptr(x), _ptr(s), _ptr(out, bf16_ok=True), rows, cols, _st(out), _stream()),

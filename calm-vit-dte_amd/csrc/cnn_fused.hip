@@ -44,8 +44,9 @@ constexpr int FW_NT = 256;
 constexpr int FG = FW_NT / 16;  // 16 pixel groups
 constexpr int FH = T + 2;       // h1 region edge (halo 1)
 
+// res: 1.f = out = x + proj(x) (the Block / ViT forward), 0.f = the bare proj(x)
 __global__ __launch_bounds__(FW_NT) void cnn_fwd_kernel(const float* __restrict__ x, CnnW W, float* __restrict__ out,
-                                                        int B, int S, int tiles_per_side, long n_tiles) {
+                                                        int B, int S, int tiles_per_side, long n_tiles, float res) {
     __shared__ float xs[FH * FH * 3];
     __shared__ __attribute__((aligned(16))) float hs[FH * FH * PS];   // h1 on 18x18; later h2 on the 16x16 tile
     __shared__ float w4s[3 * CH + 3];
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(FW_NT) void cnn_fwd_kernel(const float* __restrict_
                 }
                 const int pc = ((qy + 1) * FH + qx + 1) * 3;
                 float* ob = out + ((long)b * S * S + (long)yy * S + xx) * 3;
-                ob[0] = o0 + xs[pc]; ob[1] = o1 + xs[pc + 1]; ob[2] = o2 + xs[pc + 2];
+                ob[0] = fmaf(res, xs[pc], o0); ob[1] = fmaf(res, xs[pc + 1], o1); ob[2] = fmaf(res, xs[pc + 2], o2);
             }
         }
     }
@@ -142,12 +143,11 @@ constexpr int BG = BW_NT / 16;   // 32 pixel groups
 constexpr int H2 = T + 4;        // h1 region edge (halo 2) = 20
 constexpr int H1 = T + 2;        // dh2p region edge (halo 1) = 18
 
+constexpr int CNN_PART_N = 17 * CH + 3, CNN_PART_STRIDE = 560;      // one row of weight-gradient partials per workgroup
+static_assert(CNN_PART_N <= CNN_PART_STRIDE, "partial row");
 __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, CnnW W,
-                                                        float* __restrict__ dx, float* __restrict__ g0,
-                                                        float* __restrict__ gb0, float* __restrict__ g2,
-                                                        float* __restrict__ gb2, float* __restrict__ g4,
-                                                        float* __restrict__ gb4, int B, int S, int tiles_per_side,
-                                                        long n_tiles) {
+                                                        float* __restrict__ dx, float* __restrict__ part, int B, int S,
+                                                        int tiles_per_side, long n_tiles, float res) {
     __shared__ float xs[H2 * H2 * 3];
     __shared__ float dys[H1 * H1 * 3];
     __shared__ __attribute__((aligned(16))) float h1s[H2 * H2 * PS];   // h1 on 20x20; later dh1p on the tile
@@ -286,6 +286,7 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
                 const int pd = ((qy + 1) * H1 + qx + 1) * 3;
                 float o0 = dys[pd], o1 = dys[pd + 1], o2 = dys[pd + 2];
                 a_gb4[0] += o0; a_gb4[1] += o1; a_gb4[2] += o2;
+                o0 *= res; o1 *= res; o2 *= res;                       // the skip connection's share of dx
 #pragma unroll
                 for (int cc = 0; cc < CH; cc += 2) {
                     const f32x2 d = ld2(&h1s[q * PS + cc]);
@@ -298,7 +299,11 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
             }
         }
     }
-    // ---- block reduction of the weight-gradient accumulators, one atomic per element per block ----
+    // ---- block reduction of the weight-gradient accumulators (fixed order) into the block's row of partials:
+    //      [g0 3CH | gb0 CH | g2 9CH | gb2 CH | g4 3CH | gb4 3], combined over the blocks by calm_reduce_partials ----
+    float* const prow = part + (long)blockIdx.x * CNN_PART_STRIDE;
+    float* const g0 = prow, * const gb0 = prow + 3 * CH, * const g2 = prow + 4 * CH, * const gb2 = prow + 13 * CH,
+               * const g4 = prow + 14 * CH, * const gb4 = prow + 17 * CH;
     auto reduce_c = [&](f32x2 v, float* dst0, int stride) {   // sum over the 32 pixel groups for channels c, c+1
         __syncthreads();
         red[g * CH + c] = v[0];
@@ -308,7 +313,7 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < BG; ++k) s += red[k * CH + tid];
-            atomicAdd(dst0 + tid * stride, s);
+            dst0[tid * stride] = s;
         }
     };
 #pragma unroll
@@ -328,7 +333,7 @@ __global__ __launch_bounds__(BW_NT) void cnn_bwd_kernel(const float* __restrict_
         if (tid == 0) {
             float s = 0.f;
             for (int k = 0; k < BW_NT / 64; ++k) s += red[k];
-            atomicAdd(gb4 + o, s);
+            gb4[o] = s;
         }
     }
 }
@@ -339,7 +344,7 @@ extern "C" {
 
 int calm_cnn_residual_fwd(const float* x, const float* w0, const float* s0, const float* b0, const float* w2,
                           const float* s2, const float* b2, const float* w4, const float* s4, const float* b4,
-                          float* out, int32_t B, int32_t S, int32_t hidden, void* stream) {
+                          float* out, int32_t B, int32_t S, int32_t hidden, int32_t residual, void* stream) {
     if (!x || !w0 || !s0 || !b0 || !w2 || !s2 || !b2 || !w4 || !s4 || !b4 || !out || B <= 0 || S <= 0)
         return CALM_E_INVAL;
     if (hidden != CH) return CALM_E_UNSUPP;
@@ -347,7 +352,8 @@ int calm_cnn_residual_fwd(const float* x, const float* w0, const float* s0, cons
     const long n_tiles = (long)B * tps * tps;
     const int grid = (int)(n_tiles < 256 * 6 ? n_tiles : 256 * 6);
     CnnW W{w0, s0, b0, w2, s2, b2, w4, s4, b4};
-    hipLaunchKernelGGL(cnn_fwd_kernel, dim3(grid), dim3(FW_NT), 0, as_stream(stream), x, W, out, B, S, tps, n_tiles);
+    hipLaunchKernelGGL(cnn_fwd_kernel, dim3(grid), dim3(FW_NT), 0, as_stream(stream), x, W, out, B, S, tps, n_tiles,
+                       residual ? 1.f : 0.f);
     CALM_LAUNCH_CHECK();
     return 0;
 }
@@ -355,17 +361,25 @@ int calm_cnn_residual_fwd(const float* x, const float* w0, const float* s0, cons
 int calm_cnn_residual_bwd(const float* dy, const float* x, const float* w0, const float* s0, const float* b0,
                           const float* w2, const float* s2, const float* b2, const float* w4, const float* s4,
                           const float* b4, float* dx, float* g0, float* gb0, float* g2, float* gb2, float* g4,
-                          float* gb4, int32_t B, int32_t S, int32_t hidden, void* stream) {
+                          float* gb4, int32_t B, int32_t S, int32_t hidden, int32_t residual, float* partials,
+                          void* stream) {
     if (!dy || !x || !w0 || !s0 || !b0 || !w2 || !s2 || !b2 || !w4 || !s4 || !b4 || !dx || !g0 || !gb0 || !g2 ||
-        !gb2 || !g4 || !gb4 || B <= 0 || S <= 0)
+        !gb2 || !g4 || !gb4 || !partials || B <= 0 || S <= 0)
         return CALM_E_INVAL;
     if (hidden != CH) return CALM_E_UNSUPP;
     const int tps = (S + T - 1) / T;
     const long n_tiles = (long)B * tps * tps;
     const int grid = (int)(n_tiles < 256 ? n_tiles : 256);
     CnnW W{w0, s0, b0, w2, s2, b2, w4, s4, b4};
-    hipLaunchKernelGGL(cnn_bwd_kernel, dim3(grid), dim3(BW_NT), 0, as_stream(stream), dy, x, W, dx, g0, gb0, g2, gb2,
-                       g4, gb4, B, S, tps, n_tiles);
+    hipLaunchKernelGGL(cnn_bwd_kernel, dim3(grid), dim3(BW_NT), 0, as_stream(stream), dy, x, W, dx, partials, B, S, tps,
+                       n_tiles, residual ? 1.f : 0.f);
+    CALM_LAUNCH_CHECK();
+    CalmReduceDst d{};
+    d.out[0] = g0; d.out[1] = gb0; d.out[2] = g2; d.out[3] = gb2; d.out[4] = g4; d.out[5] = gb4;
+    d.begin[0] = 0; d.begin[1] = 3 * CH; d.begin[2] = 4 * CH; d.begin[3] = 13 * CH; d.begin[4] = 14 * CH;
+    d.begin[5] = 17 * CH; d.begin[6] = CNN_PART_N; d.nseg = 6;
+    hipLaunchKernelGGL(calm_reduce_partials_kernel, dim3((CNN_PART_N + 63) / 64), dim3(256), 0, as_stream(stream),
+                       partials, grid, CNN_PART_N, CNN_PART_STRIDE, d);
     CALM_LAUNCH_CHECK();
     return 0;
 }

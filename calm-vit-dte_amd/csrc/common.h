@@ -84,3 +84,44 @@ __device__ __forceinline__ float block_max_256(float v, float* red) {
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- fixed-order cross-workgroup reductions (ABI v7) -------------------------------------------------------------------
+// Sums that span workgroups (LayerNorm dw, RoPE d_inv_freq, bias column sums, the latent KL sum, the CNN tail's weight
+// gradients) are two-stage: workgroup g writes its partial row to partials[g * stride .. + n) (caller-provided scratch)
+// and this second launch adds the G rows in a fixed tree over g — four row lanes (g mod 4), each with two running sums
+// in increasing g, combined as (l0 + l1) + (l2 + l3) — and ADDS the result to the output.  No atomics: the result
+// repeats bit for bit.  (Rounds 1-3 left every workgroup with one fp32 atomic per output element, which made the
+// backward differ in the last bits from run to run.)  Up to six output tensors side by side in one partial row:
+// columns [begin[k], begin[k + 1]) go to out[k].
+struct CalmReduceDst {
+    float* out[6];
+    int begin[7];
+    int nseg;
+};
+static __global__ __launch_bounds__(256) void calm_reduce_partials_kernel(const float* __restrict__ part, int G, int n,
+                                                                         int stride, const CalmReduceDst dst) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < n) {
+        int g = rg;
+        for (; g + 4 < G; g += 8) {                      // two loads in flight per thread
+            s0 += part[(long)g * stride + c];
+            s1 += part[(long)(g + 4) * stride + c];
+        }
+        if (g < G) s0 += part[(long)g * stride + c];
+    }
+    red[rg][lane] = s0 + s1;
+    __syncthreads();
+    if (rg == 0 && c < n) {
+        int k = 0;
+        while (k + 1 < dst.nseg && c >= dst.begin[k + 1]) ++k;
+        dst.out[k][c - dst.begin[k]] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    }
+}
+static inline void calm_reduce_partials(const float* part, int G, int n, float* out, hipStream_t s) {
+    CalmReduceDst d{};
+    d.out[0] = out; d.begin[0] = 0; d.begin[1] = n; d.nseg = 1;
+    hipLaunchKernelGGL(calm_reduce_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, part, G, n, n, d);
+}

@@ -52,11 +52,14 @@ inline bool mult4(int64_t x) { return (x & 3) == 0; }
 constexpr int PIPE_DECLINED = -1000;
 
 static std::atomic<int>& pipe_option(int which) {
-    static std::atomic<int> opt[2] = {
+    static std::atomic<int> opt[3] = {
         [] { const char* e = getenv("CALM_GEMM_PIPE"); return (e && e[0] == '0') ? 0 : 1; }(),
-        [] { const char* e = getenv("CALM_GEMM_PIPE32"); return e ? atoi(e) : 0; }()};
+        [] { const char* e = getenv("CALM_GEMM_PIPE32"); return e ? atoi(e) : 0; }(),
+        [] { const char* e = getenv("CALM_GEMM_DETERMINISTIC"); return (e && e[0] == '1') ? 1 : 0; }()};
     return opt[which];
 }
+// every k-split / batch-reduced launch through the workspace + fixed-order reduction (no fp32 atomics)
+static bool deterministic() { return pipe_option(CALM_GEMM_OPT_DETERMINISTIC).load(std::memory_order_relaxed) != 0; }
 static bool pipe_enabled() { return pipe_option(CALM_GEMM_OPT_PIPE).load(std::memory_order_relaxed) != 0; }
 // fp32 instantiation: 0 off (default), 1 every eligible launch, 2 k-contiguous operand pairs only
 static int pipe32_mode() { return pipe_enabled() ? pipe_option(CALM_GEMM_OPT_PIPE32).load(std::memory_order_relaxed) : 0; }
@@ -73,7 +76,8 @@ static double pipe_cost(long items, int mt, int nt, int nk, bool split, bool f32
     return rounds * (nk * ktile + epi);
 }
 
-static int pipe_run(const calm_gemm_args* a, GemmP& p, bool akc, bool bkc, bool f32, hipStream_t s, int64_t* query) {
+static int pipe_run(const calm_gemm_args* a, GemmP& p, bool akc, bool bkc, bool f32, hipStream_t s, int64_t* query,
+                    calm_gemm_plan* plan) {
     if (!akc && bkc) return PIPE_DECLINED;                      // row-contiguous A with k-contiguous B: not instantiated
     if (a->reduce_batch || !p.epi_vec) return PIPE_DECLINED;
     if ((a->act == CALM_ACT_GELU_BWD) + (a->residual != nullptr) + (a->accumulate != 0) > 1) return PIPE_DECLINED;   // one C-shaped epilogue operand
@@ -157,13 +161,23 @@ static int pipe_run(const calm_gemm_args* a, GemmP& p, bool akc, bool bkc, bool 
     p.ws = nullptr;
     p.ws_slice = (long)a->M * a->N;
     int64_t ws_need = 0;
-    if (p.atomic && slices_per_out >= CALM_GEMM_WS_MIN_SLICES && p.ws_slice >= 100000)
+    if (p.atomic && (deterministic() || (slices_per_out >= CALM_GEMM_WS_MIN_SLICES && p.ws_slice >= 100000)))
         ws_need = (int64_t)sizeof(float) * p.nz * p.ws_slice;
     if (query) {
         *query = ws_need;
         return 0;
     }
     const bool use_ws = ws_need > 0 && a->workspace && a->workspace_bytes >= ws_need && aligned16(a->workspace);
+    if (plan) {
+        const long items_ = (long)p.tiles_m * p.tiles_n * p.nz;
+        const bool u8_ = !p.atomic && a->c_type == CALM_ST_BF16 && (!a->aux || a->aux_type == CALM_ST_BF16) &&
+                         (!a->residual || (a->r_type == CALM_ST_BF16 && !(a->r_rs & 7) && !(a->r_b0 & 7) && !(a->r_b1 & 7))) &&
+                         !(a->N & 7) && !(a->c_rs & 7) && !(a->c_b0 & 7) && !(a->c_b1 & 7);
+        *plan = calm_gemm_plan{f32 ? 4 : 3, 64 * mt, 32 * nt, f32 ? 32 : 64, p.tiles_m, p.tiles_n, slices_per_out,
+                               (int32_t)items_, (int32_t)(items_ < 256 ? items_ : 256), u8_ ? 8 : 4, use_ws ? 1 : 0,
+                               512};
+        return 0;
+    }
     if (use_ws) {
         p.ws = (float*)a->workspace;
     } else if (p.atomic && !a->accumulate) {
@@ -210,8 +224,9 @@ static int pipe_run(const calm_gemm_args* a, GemmP& p, bool akc, bool bkc, bool 
     return 0;
 }
 
-// query != nullptr: plan only and report the workspace size of the launch (calm_gemm_workspace_bytes)
-static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
+// query != nullptr: plan only and report the workspace size of the launch (calm_gemm_workspace_bytes);
+// plan != nullptr: plan only and describe the launch (calm_gemm_describe)
+static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query, calm_gemm_plan* plan = nullptr) {
     if (!a || !a->A || !a->B || !a->C) return CALM_E_INVAL;
     if (a->M <= 0 || a->N <= 0 || a->K <= 0 || a->batch0 <= 0 || a->batch1 <= 0) return CALM_E_INVAL;
     if (a->dtype != CALM_F32 && a->dtype != CALM_BF16 && a->dtype != CALM_BF16X3) return CALM_E_UNSUPP;
@@ -290,6 +305,11 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
             *query = 0;
             return 0;
         }
+        if (plan) {
+            *plan = calm_gemm_plan{5, WBM, WBN, 64, p.tiles_m, p.tiles_n, 1, p.tiles_m * p.tiles_n * batch,
+                                   p.tiles_m * p.tiles_n * batch, 0, 0, WTHREADS};
+            return 0;
+        }
         return launch_fp8(p, dim3(p.tiles_m * p.tiles_n, batch), s);
     }
     // 16-byte staging vectors hold 4 fp32 or 8 bf16 elements: sizes / strides of an operand must be multiples of that
@@ -305,11 +325,11 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
     if (!vec && any_bf16_tensor) return CALM_E_LAYOUT;
     const int family = vec ? a->dtype : CALM_F32;
     if (family == CALM_BF16 && a->a_type == CALM_ST_BF16 && a->b_type == CALM_ST_BF16 && pipe_enabled()) {
-        const int rc = pipe_run(a, p, akc, bkc, false, s, query);
+        const int rc = pipe_run(a, p, akc, bkc, false, s, query, plan);
         if (rc != PIPE_DECLINED) return rc;
     }
     if (vec && a->dtype == CALM_F32 && !any_bf16_tensor && (pipe32_mode() == 1 || (pipe32_mode() == 2 && akc && bkc))) {
-        const int rc = pipe_run(a, p, akc, bkc, true, s, query);
+        const int rc = pipe_run(a, p, akc, bkc, true, s, query, plan);
         if (rc != PIPE_DECLINED) return rc;
     }
     const int bk = family == CALM_F32 ? BK : CK;
@@ -433,13 +453,20 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
     p.ws = nullptr;
     p.ws_slice = (long)a->M * a->N;
     int64_t ws_need = 0;
-    if (p.atomic && slices_per_out >= CALM_GEMM_WS_MIN_SLICES && p.ws_slice >= 100000)     // tiny outputs: the second launch costs more than their atomics
+    if (p.atomic && (deterministic() || (slices_per_out >= CALM_GEMM_WS_MIN_SLICES && p.ws_slice >= 100000)))     // tiny outputs: the second launch costs more than their atomics
         ws_need = (int64_t)sizeof(float) * gy * p.ws_slice;
     if (query) {
         *query = ws_need;
         return 0;
     }
     const bool use_ws = ws_need > 0 && a->workspace && a->workspace_bytes >= ws_need && aligned16(a->workspace);
+    if (plan) {
+        const int fam = wide ? 2 : family == CALM_F32 ? 0 : 1;
+        *plan = calm_gemm_plan{fam, wide ? WBM : BM, bn, family == CALM_F32 ? BK : CK, p.tiles_m, p.tiles_n,
+                               p.atomic ? slices_per_out : 1, tiles * gy, tiles * gy, 0, use_ws ? 1 : 0,
+                               wide ? WTHREADS : NTHREADS};
+        return 0;
+    }
     if (use_ws) {
         p.ws = (float*)a->workspace;
     } else if (p.atomic && !a->accumulate) {
@@ -476,9 +503,15 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query) {
 extern "C" int calm_gemm(const calm_gemm_args* a, void* stream) { return gemm_run(a, stream, nullptr); }
 
 extern "C" int calm_gemm_set_option(int32_t option, int32_t value) {
-    if (option != CALM_GEMM_OPT_PIPE && option != CALM_GEMM_OPT_PIPE32) return CALM_E_INVAL;
-    if (value < 0 || value > (option == CALM_GEMM_OPT_PIPE ? 1 : 2)) return CALM_E_INVAL;
+    if (option != CALM_GEMM_OPT_PIPE && option != CALM_GEMM_OPT_PIPE32 && option != CALM_GEMM_OPT_DETERMINISTIC)
+        return CALM_E_INVAL;
+    if (value < 0 || value > (option == CALM_GEMM_OPT_PIPE32 ? 2 : 1)) return CALM_E_INVAL;
     return pipe_option(option).exchange(value);
+}
+
+extern "C" int calm_gemm_describe(const calm_gemm_args* a, calm_gemm_plan* plan) {
+    if (!plan) return CALM_E_INVAL;
+    return gemm_run(a, nullptr, nullptr, plan);
 }
 
 extern "C" int64_t calm_gemm_workspace_bytes(const calm_gemm_args* a) {

@@ -325,17 +325,36 @@ __device__ __forceinline__ void pipe_epilogue_rows(const GemmP& p, f32x4 (&acc)[
             // every C-shaped operand of the strip is requested before the first one is used: one memory round trip per
             // strip instead of one per unit (the wait for a load also waits for every older store, so loads issued
             // between the stores would each pay the store latency)
+            // The storage-type branch encloses the whole batch of loads: with the branch inside pipe_load (round 3) the
+            // bf16 side compiled to load / s_waitcnt vmcnt(0) / convert PER UNIT (ISA of <true,false,4,7>: 16 exposed
+            // round trips per tile, each of which also drained every older store).
             f32x4 t[NI][Q];
             const char* __restrict__ Tb = p_act == CALM_ACT_GELU_BWD ? Xb : Rb ? Rb : Cb;
             const long t_rs = Rb && p_act != CALM_ACT_GELU_BWD ? r_rs : c_rs;
             const int t_type = p_act == CALM_ACT_GELU_BWD ? aux_type : Rb ? r_type : c_type;
+            long toff[NI];
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 int r, col;
                 bool live;
                 unit_of(i, r, col, live);
                 const long ro = min(srow + r, pM - 1);
-                pipe_load<UNIT>(Tb, ro * t_rs + (col < pN ? col : 0), t_type, t[i]);
+                toff[i] = ro * t_rs + (col < pN ? col : 0);
+            }
+            if (t_type == CALM_ST_BF16) {
+                typedef __bf16 praw __attribute__((ext_vector_type(UNIT)));
+                praw h[NI];
+#pragma unroll
+                for (int i = 0; i < NI; ++i) h[i] = *reinterpret_cast<const praw*>(Tb + toff[i] * 2);
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int e = 0; e < UNIT; ++e) t[i][e >> 2][e & 3] = (float)h[i][e];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) t[i][q] = *reinterpret_cast<const f32x4*>(Tb + toff[i] * 4 + 16 * q);
             }
 #pragma unroll
             for (int i = 0; i < NI; ++i) {

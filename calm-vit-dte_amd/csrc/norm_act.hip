@@ -1,8 +1,9 @@
 // HBM-bound streaming kernels of the CALM-ViT path: LayerNorm, learned RoPE + head assembly,
 // row softmax, latent sampling/KL, and small helpers.  All are one-wave-per-row or grid-stride
 // kernels with coalesced (16-byte where alignment allows) accesses and wave shuffles for the
-// row reductions; cross-row reductions (dw, d_inv_freq, kl, bias grads) are summed per block
-// in registers/LDS first and leave the block as one atomic per output element.
+// row reductions; cross-row reductions (dw, d_inv_freq, kl, bias grads) are summed per block in registers / LDS in a
+// fixed order, leave the block as one row of caller-provided scratch and are combined by calm_reduce_partials
+// (common.h) in workgroup order: no atomics, every result repeats bit for bit (ABI v7).
 #include "common.h"
 
 namespace {
@@ -52,7 +53,7 @@ template <bool G16>
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                     const float* __restrict__ w, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, float* __restrict__ dx,
-                                                    float* __restrict__ dw, const float* __restrict__ dx_add,
+                                                    float* __restrict__ dw_part, const float* __restrict__ dx_add,
                                                     long rows, int D) {
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const void* __restrict__ dy_
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < NT / 64; ++k) s += red[k * (64 * LN_MAXC) + c];
-        atomicAdd(dw + c, s);
+        dw_part[(long)blockIdx.x * D + c] = s;
     }
 }
 
@@ -158,7 +159,7 @@ template <int NV, bool G16>
 __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const void* __restrict__ dy_, const float* __restrict__ x,
                                                         const float* __restrict__ w, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, float* __restrict__ dx,
-                                                        float* __restrict__ dw, const float* __restrict__ dx_add,
+                                                        float* __restrict__ dw_part, const float* __restrict__ dx_add,
                                                         long rows, int D) {
     const int lane = threadIdx.x & 63;
     const long wave = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6);
@@ -221,8 +222,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const void* __restrict__
             }
         }
     }
-    // block-level reduction of dw over the 4 waves, then ONE atomic per column per block (per-wave atomics
-    // on the same D addresses from thousands of waves cost a ~400 us floor per call)
+    // block-level reduction of dw over the 4 waves (fixed order), then the block's row of partials
     __shared__ float red[(NT / 64) * 256 * NV * 4];
     const int wv_id = threadIdx.x >> 6;
 #pragma unroll
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const void* __restrict__
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < NT / 64; ++k) s += red[k * (256 * NV) + c];
-        atomicAdd(dw + c, s);
+        dw_part[(long)blockIdx.x * D + c] = s;
     }
 }
 
@@ -295,42 +295,6 @@ constexpr int ROPE_MAX_HALF = 256;
 #ifndef CALM_ROPE_BWD_GRID
 #define CALM_ROPE_BWD_GRID 1024
 #endif
-
-__global__ __launch_bounds__(NT) void rope_bwd_kernel(const void* __restrict__ d_out, const void* __restrict__ xr,
-                                                      const float* __restrict__ table, void* __restrict__ d_content,
-                                                      void* __restrict__ d_xr, float* __restrict__ d_inv_freq,
-                                                      long nrows, int S, int H, int dc, int dr, int dout_type,
-                                                      int xr_type, int dcontent_type, int dxr_type) {
-    __shared__ float facc[ROPE_MAX_HALF];
-    const int half = dr >> 1;
-    for (int j = threadIdx.x; j < half; j += NT) facc[j] = 0.f;
-    __syncthreads();
-    const int wd = dc + half;
-    const long total = nrows * wd;
-    const float* cosT = table;
-    const float* sinT = table + (long)S * half;
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
-        const long row = i / wd;
-        const int j = (int)(i - row * wd);
-        const long go = row * (dc + dr);
-        if (j < dc) {
-            stt(d_content, row * dc + j, ldt(d_out, go + j, dout_type), dcontent_type);
-        } else {
-            const int jj = j - dc;
-            const int s = (int)((row / H) % S);
-            const float c = cosT[s * half + jj], sn = sinT[s * half + jj];
-            const float g1 = ldt(d_out, go + dc + jj, dout_type), g2 = ldt(d_out, go + dc + jj + half, dout_type);
-            const float x1 = ldt(xr, row * dr + jj, xr_type), x2 = ldt(xr, row * dr + jj + half, xr_type);
-            stt(d_xr, row * dr + jj, g1 * c + g2 * sn, dxr_type);
-            stt(d_xr, row * dr + jj + half, g2 * c - g1 * sn, dxr_type);
-            // d/d(angle): y1 = x1 c - x2 s, y2 = x2 c + x1 s ; angle = s * inv_freq[jj]
-            const float dang = g1 * (-x1 * sn - x2 * c) + g2 * (-x2 * sn + x1 * c);
-            atomicAdd(&facc[jj], dang * (float)s);
-        }
-    }
-    __syncthreads();
-    for (int j = threadIdx.x; j < half; j += NT) atomicAdd(d_inv_freq + j, facc[j]);
-}
 
 // ---- row-walking form ----
 // The one-element-per-thread kernels above cost a 64-bit division per element, an LDS atomic per rotated pair and, on
@@ -433,14 +397,12 @@ __global__ __launch_bounds__(NT) void rope_fwd_vec_kernel(const void* __restrict
 template <int VW>
 __global__ __launch_bounds__(NT) void rope_bwd_vec_kernel(const void* __restrict__ d_out, const void* __restrict__ xr,
                                                           const float* __restrict__ table, void* __restrict__ d_content,
-                                                          void* __restrict__ d_xr, float* __restrict__ d_inv_freq,
+                                                          void* __restrict__ d_xr, float* __restrict__ dif_part,
                                                           int nrows, int S, int H, int dc, int dr, int dout_type,
                                                           int xr_type, int dcontent_type, int dxr_type) {
     typedef typename RopeVec<VW>::type vec;
-    __shared__ float facc[ROPE_MAX_HALF];
+    __shared__ float facc[NT * VW];                    // [row lane][rotation pair]: rpb * half <= NT * VW floats
     const int half = dr >> 1, ir = half / VW, ic = dc / VW;
-    for (int k = threadIdx.x; k < half; k += NT) facc[k] = 0.f;
-    __syncthreads();
     const int rpb = NT / ir;
     const int r_in = threadIdx.x / ir, j = threadIdx.x - r_in * ir;
     const int jj = VW * j;
@@ -464,14 +426,19 @@ __global__ __launch_bounds__(NT) void rope_bwd_vec_kernel(const void* __restrict
             acc += dang * (float)s;
         }
         if constexpr (VW == 1) {
-            atomicAdd(&facc[jj], acc);
+            facc[r_in * half + jj] = acc;
         } else {
 #pragma unroll
-            for (int e = 0; e < VW; ++e) atomicAdd(&facc[jj + e], acc[e]);
+            for (int e = 0; e < VW; ++e) facc[r_in * half + jj + e] = acc[e];
         }
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < half; k += NT) atomicAdd(d_inv_freq + k, facc[k]);
+    // the row lanes of the block in lane order, then the block's row of partials (calm_reduce_partials adds the blocks)
+    for (int k = threadIdx.x; k < half; k += NT) {
+        float s = 0.f;
+        for (int r = 0; r < rpb; ++r) s += facc[r * half + k];
+        dif_part[(long)blockIdx.x * half + k] = s;
+    }
 }
 
 // ------------------------------------------------------------------ softmax (one wave per row)
@@ -594,7 +561,7 @@ __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log
 
 __global__ __launch_bounds__(NT) void latent_fwd_kernel(const float* __restrict__ mv, const float* __restrict__ noise,
                                                         float* __restrict__ z, float* __restrict__ std_out,
-                                                        float* __restrict__ kl_sum, long rows, int mvh) {
+                                                        float* __restrict__ kl_part, long rows, int mvh) {
     __shared__ float red[4];
     const long total = rows * mvh;
     float acc = 0.f;
@@ -609,7 +576,7 @@ __global__ __launch_bounds__(NT) void latent_fwd_kernel(const float* __restrict_
         acc += 1.0f + 2.0f * logf(sd) - mean * mean - sd * sd;
     }
     acc = block_sum_256(acc, red);
-    if (threadIdx.x == 0) atomicAdd(kl_sum, acc);
+    if (threadIdx.x == 0) kl_part[blockIdx.x] = acc;
 }
 
 __global__ __launch_bounds__(NT) void latent_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ d_kl_sum,
@@ -645,6 +612,10 @@ __global__ __launch_bounds__(NT) void add_kernel(const float* __restrict__ a, co
     for (long i = 4 * n4 + (long)blockIdx.x * NT + threadIdx.x; i < n; i += stride) out[i] = a[i] + b[i];
 }
 
+__global__ __launch_bounds__(NT) void gelu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) y[i] = gelu_erf_f(x[i]);
+}
+
 __global__ __launch_bounds__(NT) void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z,
                                                       float* __restrict__ dz, long n) {
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT)
@@ -655,33 +626,39 @@ constexpr int COLSUM_MAXC = 4096;
 #ifndef COLSUM_GRID
 #define COLSUM_GRID 128      // A/B on [57344,448]: 66 us (scalar form) -> 28.6 us; 256 blocks: 39.6 (atomics), 128x256 threads: 34
 #endif
-__global__ __launch_bounds__(NT) void colsum_kernel(const void* __restrict__ x, float* __restrict__ out, long rows,
+__global__ __launch_bounds__(NT) void colsum_kernel(const void* __restrict__ x, float* __restrict__ part, long rows,
                                                     int cols, int x_type) {
-    __shared__ float acc[COLSUM_MAXC];
-    for (int c = threadIdx.x; c < cols; c += NT) acc[c] = 0.f;
-    __syncthreads();
+    // block owns the rows r = blockIdx.x (mod gridDim.x); partial row of the block -> part[blockIdx.x * cols ..]
     if (cols >= NT) {
-        // thread owns columns tid, tid+256, ...; block owns a strided set of rows
+        // thread owns columns tid, tid+256, ...
         for (int c = threadIdx.x; c < cols; c += NT) {
             float s = 0.f;
             for (long r = blockIdx.x; r < rows; r += gridDim.x) s += ldt(x, r * cols + c, x_type);
-            acc[c] = s;
+            part[(long)blockIdx.x * cols + c] = s;
         }
     } else {
-        const long total = rows * cols;
-        for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT)
-            atomicAdd(&acc[(int)(i % cols)], ldt(x, i, x_type));
+        // NT / cols row lanes, each thread one column of its rows; the lanes meet in LDS in lane order
+        __shared__ float acc[NT];
+        const int rl_n = NT / cols, rl = threadIdx.x / cols, c = threadIdx.x - rl * cols;
+        float s = 0.f;
+        if (rl < rl_n)
+            for (long r = (long)blockIdx.x * rl_n + rl; r < rows; r += (long)gridDim.x * rl_n) s += ldt(x, r * cols + c, x_type);
+        acc[threadIdx.x] = s;
+        __syncthreads();
+        if (threadIdx.x < cols) {
+            float t = 0.f;
+            for (int k = 0; k < rl_n; ++k) t += acc[k * cols + threadIdx.x];
+            part[(long)blockIdx.x * cols + threadIdx.x] = t;
+        }
     }
-    __syncthreads();
-    for (int c = threadIdx.x; c < cols; c += NT) atomicAdd(out + c, acc[c]);
 }
 
 // 16-byte form: TX lanes across the row (one float4 each, several passes if the row is longer), 1024/TX row lanes,
-// four rows in flight per thread; partial sums meet in LDS, one atomic per column per block.
+// four rows in flight per thread; partial sums meet in LDS in lane order, one row of partials per block.
 constexpr int CS_NT = 1024;          // 16 waves per block: few blocks (few atomics per column), many rows in flight
 // X16: x is a bf16 tensor (8-byte loads of 4 elements; the sums stay fp32)
 template <int TX, bool X16>
-__global__ __launch_bounds__(CS_NT) void colsum_vec_kernel(const void* __restrict__ x_, float* __restrict__ out, long rows,
+__global__ __launch_bounds__(CS_NT) void colsum_vec_kernel(const void* __restrict__ x_, float* __restrict__ prow, long rows,
                                                         int cols) {
     auto ld = [&](long r, int c4) -> f32x4 {
         if constexpr (X16) {
@@ -714,8 +691,7 @@ __global__ __launch_bounds__(CS_NT) void colsum_vec_kernel(const void* __restric
             f32x4 s = part[tx];
 #pragma unroll
             for (int k = 1; k < TY; ++k) s += part[k * TX + tx];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) atomicAdd(out + 4 * c4 + e, s[e]);
+            *reinterpret_cast<f32x4*>(prow + (long)blockIdx.x * cols + 4 * c4) = s;
         }
         __syncthreads();
     }
@@ -791,15 +767,19 @@ int calm_layernorm_fwd(const float* x, const float* w, void* y, float* mean, flo
     return 0;
 }
 
+static int ln_bwd_grid(int64_t rows) {
+    const int g = grid_for(rows, NT / 64);
+    return g > 512 ? 512 : g;
+}
+
 int calm_layernorm_bwd(const void* dy, const float* x, const float* w, const float* mean, const float* rstd,
                        float* dx, float* dw, const float* dx_add, int64_t rows, int32_t D, int32_t dy_type,
-                       void* stream) {
-    if (!dy || !x || !w || !mean || !rstd || !dx || !dw || rows <= 0 || D <= 0) return CALM_E_INVAL;
+                       float* partials, void* stream) {
+    if (!dy || !x || !w || !mean || !rstd || !dx || !dw || !partials || rows <= 0 || D <= 0) return CALM_E_INVAL;
     if (dy_type != CALM_ST_F32 && dy_type != CALM_ST_BF16) return CALM_E_INVAL;
     if (D > 64 * LN_MAXC) return CALM_E_UNSUPP;
     const bool g16 = dy_type == CALM_ST_BF16;
-    int g = grid_for(rows, NT / 64);
-    if (g > 512) g = 512;
+    const int g = ln_bwd_grid(rows);
     hipStream_t s = as_stream(stream);
     const dim3 gd(g), b(NT);
     if ((D & 3) == 0 && D <= 256 * 5 && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(w) &&
@@ -807,8 +787,8 @@ int calm_layernorm_bwd(const void* dy, const float* x, const float* w, const flo
         const int nv = (D / 4 + 63) / 64;
 #define LN_BWD(NVV)                                                                                                        \
     do {                                                                                                                   \
-        if (g16) hipLaunchKernelGGL((ln_bwd_vec_kernel<NVV, true>), gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D); \
-        else hipLaunchKernelGGL((ln_bwd_vec_kernel<NVV, false>), gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D);    \
+        if (g16) hipLaunchKernelGGL((ln_bwd_vec_kernel<NVV, true>), gd, b, 0, s, dy, x, w, mean, rstd, dx, partials, dx_add, (long)rows, D); \
+        else hipLaunchKernelGGL((ln_bwd_vec_kernel<NVV, false>), gd, b, 0, s, dy, x, w, mean, rstd, dx, partials, dx_add, (long)rows, D);    \
     } while (0)
         switch (nv) {
             case 1: LN_BWD(1); break;
@@ -819,10 +799,14 @@ int calm_layernorm_bwd(const void* dy, const float* x, const float* w, const flo
         }
 #undef LN_BWD
         CALM_LAUNCH_CHECK();
+        calm_reduce_partials(partials, g, D, dw, s);
+        CALM_LAUNCH_CHECK();
         return 0;
     }
-    if (g16) hipLaunchKernelGGL(ln_bwd_kernel<true>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D);
-    else hipLaunchKernelGGL(ln_bwd_kernel<false>, gd, b, 0, s, dy, x, w, mean, rstd, dx, dw, dx_add, (long)rows, D);
+    if (g16) hipLaunchKernelGGL(ln_bwd_kernel<true>, gd, b, 0, s, dy, x, w, mean, rstd, dx, partials, dx_add, (long)rows, D);
+    else hipLaunchKernelGGL(ln_bwd_kernel<false>, gd, b, 0, s, dy, x, w, mean, rstd, dx, partials, dx_add, (long)rows, D);
+    CALM_LAUNCH_CHECK();
+    calm_reduce_partials(partials, g, D, dw, s);
     CALM_LAUNCH_CHECK();
     return 0;
 }
@@ -874,41 +858,41 @@ int calm_rope_fwd(const void* content, const void* xr, const float* inv_freq, fl
     return 0;
 }
 
+static int rope_bwd_grid(long nrows, int dc, int dr) {
+    int gv = rope_vec_grid(nrows, dc, dr);
+    // every workgroup ends with a row of dr/2 partials: few workgroups for small launches (A/B at S=80 with the
+    // atomics of rounds 1-3: 1024 -> 25 us, 2048 -> 36, 4096 -> 60), ~16 row passes per workgroup for large ones
+    const int want = gv / 16;
+    return want < CALM_ROPE_BWD_GRID ? (gv < CALM_ROPE_BWD_GRID ? gv : CALM_ROPE_BWD_GRID) : (want < 4096 ? want : 4096);
+}
+
 int calm_rope_bwd(const void* d_out, const void* xr, const float* table, void* d_content, void* d_xr,
                   float* d_inv_freq, int32_t B, int32_t S, int32_t H, int32_t dc, int32_t dr, int32_t dout_type,
-                  int32_t xr_type, int32_t dcontent_type, int32_t dxr_type, void* stream) {
-    if (!d_out || !xr || !table || !d_xr || !d_inv_freq || B <= 0 || S <= 0 || H <= 0 || dc < 0 || dr <= 0 ||
-        (dr & 1))
+                  int32_t xr_type, int32_t dcontent_type, int32_t dxr_type, float* partials, void* stream) {
+    if (!d_out || !xr || !table || !d_xr || !d_inv_freq || !partials || B <= 0 || S <= 0 || H <= 0 || dc < 0 ||
+        dr <= 0 || (dr & 1))
         return CALM_E_INVAL;
     if (dc > 0 && !d_content) return CALM_E_INVAL;
     if (!st_ok(dout_type) || !st_ok(xr_type) || !st_ok(dcontent_type) || !st_ok(dxr_type)) return CALM_E_INVAL;
-    if (dr / 2 > ROPE_MAX_HALF) return CALM_E_UNSUPP;
     const long nrows = (long)B * S * H;
-    if (rope_vec_ok(nrows, dc, dr)) {
-        int gv = rope_vec_grid(nrows, dc, dr);
-        // every workgroup ends with dr/2 atomics on one cache line of d_inv_freq: few workgroups for small launches
-        // (A/B at S=80: 1024 -> 25 us, 2048 -> 36, 4096 -> 60), ~16 row passes per workgroup for large ones
-        const int want = gv / 16;
-        gv = want < CALM_ROPE_BWD_GRID ? (gv < CALM_ROPE_BWD_GRID ? gv : CALM_ROPE_BWD_GRID) : (want < 4096 ? want : 4096);
-        if (rope_vw(dc, dr) == 4)
-            hipLaunchKernelGGL(rope_bwd_vec_kernel<4>, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table,
-                               d_content, d_xr, d_inv_freq, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type,
-                               dxr_type);
-        else if (rope_vw(dc, dr) == 2)
-            hipLaunchKernelGGL(rope_bwd_vec_kernel<2>, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table,
-                               d_content, d_xr, d_inv_freq, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type,
-                               dxr_type);
-        else
-            hipLaunchKernelGGL(rope_bwd_vec_kernel<1>, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table,
-                               d_content, d_xr, d_inv_freq, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type,
-                               dxr_type);
-        CALM_LAUNCH_CHECK();
-        return 0;
-    }
-    int g = grid_for(nrows * (dc + dr / 2), NT);
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(rope_bwd_kernel, dim3(g), dim3(NT), 0, as_stream(stream), d_out, xr, table, d_content, d_xr,
-                       d_inv_freq, nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type, dxr_type);
+    // (the one-element-per-thread backward of round 1 combined its angle gradients with LDS atomics; the row-walking
+    // kernel serves every shape of the path: dr/2 <= 256 rotation pairs, tensors below 2^31 elements)
+    if (dr / 2 > ROPE_MAX_HALF || dr / 2 > NT || nrows * (dc + dr) >= (1L << 31)) return CALM_E_UNSUPP;
+    const int gv = rope_bwd_grid(nrows, dc, dr);
+    if (rope_vw(dc, dr) == 4)
+        hipLaunchKernelGGL(rope_bwd_vec_kernel<4>, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table,
+                           d_content, d_xr, partials, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type,
+                           dxr_type);
+    else if (rope_vw(dc, dr) == 2)
+        hipLaunchKernelGGL(rope_bwd_vec_kernel<2>, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table,
+                           d_content, d_xr, partials, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type,
+                           dxr_type);
+    else
+        hipLaunchKernelGGL(rope_bwd_vec_kernel<1>, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table,
+                           d_content, d_xr, partials, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type,
+                           dxr_type);
+    CALM_LAUNCH_CHECK();
+    calm_reduce_partials(partials, gv, dr / 2, d_inv_freq, as_stream(stream));
     CALM_LAUNCH_CHECK();
     return 0;
 }
@@ -950,13 +934,19 @@ int calm_sum_heads(const float* dl, float* dm, int32_t B, int32_t H, int64_t per
     return 0;
 }
 
+static int latent_grid(int64_t rows, int mvh) {
+    const int g = grid_for(rows * mvh, NT);
+    return g > 512 ? 512 : g;
+}
+
 int calm_latent_fwd(const float* mv, const float* noise, float* z, float* std_out, float* kl_sum, int64_t rows,
-                    int32_t mvh, void* stream) {
-    if (!mv || !z || !std_out || !kl_sum || rows <= 0 || mvh <= 0) return CALM_E_INVAL;
-    int g = grid_for(rows * mvh, NT);
-    if (g > 512) g = 512;
-    hipLaunchKernelGGL(latent_fwd_kernel, dim3(g), dim3(NT), 0, as_stream(stream), mv, noise, z, std_out, kl_sum,
+                    int32_t mvh, float* partials, void* stream) {
+    if (!mv || !z || !std_out || !kl_sum || !partials || rows <= 0 || mvh <= 0) return CALM_E_INVAL;
+    const int g = latent_grid(rows, mvh);
+    hipLaunchKernelGGL(latent_fwd_kernel, dim3(g), dim3(NT), 0, as_stream(stream), mv, noise, z, std_out, partials,
                        (long)rows, mvh);
+    CALM_LAUNCH_CHECK();
+    calm_reduce_partials(partials, g, 1, kl_sum, as_stream(stream));
     CALM_LAUNCH_CHECK();
     return 0;
 }
@@ -980,6 +970,13 @@ int calm_add(const float* a, const float* b, float* out, int64_t n, void* stream
     return 0;
 }
 
+int calm_gelu_fwd(const float* x, float* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0) return CALM_E_INVAL;
+    hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n, NT)), dim3(NT), 0, as_stream(stream), x, y, (long)n);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
+
 int calm_gelu_bwd(const float* dy, const float* z, float* dz, int64_t n, void* stream) {
     if (!dy || !z || !dz || n <= 0) return CALM_E_INVAL;
     hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n, NT)), dim3(NT), 0, as_stream(stream), dy, z, dz, (long)n);
@@ -987,22 +984,34 @@ int calm_gelu_bwd(const float* dy, const float* z, float* dz, int64_t n, void* s
     return 0;
 }
 
-int calm_colsum(const void* x, float* out, int64_t rows, int32_t cols, int32_t x_type, void* stream) {
-    if (!x || !out || rows <= 0 || cols <= 0) return CALM_E_INVAL;
-    if (!st_ok(x_type)) return CALM_E_INVAL;
-    if (cols > COLSUM_MAXC) return CALM_E_UNSUPP;
-    const bool x16 = x_type == CALM_ST_BF16;
-    if ((cols & 3) == 0 && aligned16(x) && rows >= 64) {
+// (vector form?, workgroups) of a column-sum launch
+static int colsum_grid(int64_t rows, int cols, bool vec, int* tx_out) {
+    if (vec) {
         const int c4n = cols >> 2;
         const int tx = c4n <= 32 ? 32 : c4n <= 64 ? 64 : c4n <= 128 ? 128 : 256;
         const int ty = CS_NT / tx;
-        long gl = (rows + (long)ty * 8 - 1) / ((long)ty * 8);          // >= 8 rows per row lane
-        const int gv = (int)(gl < 1 ? 1 : gl > COLSUM_GRID ? COLSUM_GRID : gl);   // few blocks: every block ends in `cols` atomics
-        hipStream_t s = as_stream(stream);
+        const long gl = (rows + (long)ty * 8 - 1) / ((long)ty * 8);          // >= 8 rows per row lane
+        if (tx_out) *tx_out = tx;
+        return (int)(gl < 1 ? 1 : gl > COLSUM_GRID ? COLSUM_GRID : gl);      // few blocks: every block ends in a row of partials
+    }
+    const long per = cols >= NT ? 1 : NT / cols;                              // rows per block pass
+    long g = (rows + per * 8 - 1) / (per * 8);
+    return (int)(g < 1 ? 1 : g > 512 ? 512 : g);
+}
+
+int calm_colsum(const void* x, float* out, int64_t rows, int32_t cols, int32_t x_type, float* partials, void* stream) {
+    if (!x || !out || !partials || rows <= 0 || cols <= 0) return CALM_E_INVAL;
+    if (!st_ok(x_type)) return CALM_E_INVAL;
+    if (cols > COLSUM_MAXC) return CALM_E_UNSUPP;
+    const bool x16 = x_type == CALM_ST_BF16;
+    hipStream_t s = as_stream(stream);
+    if ((cols & 3) == 0 && aligned16(x) && aligned16(partials) && rows >= 64) {
+        int tx = 0;
+        const int gv = colsum_grid(rows, cols, true, &tx);
 #define CS_LAUNCH(TXV)                                                                                              \
     do {                                                                                                            \
-        if (x16) hipLaunchKernelGGL((colsum_vec_kernel<TXV, true>), dim3(gv), dim3(CS_NT), 0, s, x, out, (long)rows, cols); \
-        else hipLaunchKernelGGL((colsum_vec_kernel<TXV, false>), dim3(gv), dim3(CS_NT), 0, s, x, out, (long)rows, cols);    \
+        if (x16) hipLaunchKernelGGL((colsum_vec_kernel<TXV, true>), dim3(gv), dim3(CS_NT), 0, s, x, partials, (long)rows, cols); \
+        else hipLaunchKernelGGL((colsum_vec_kernel<TXV, false>), dim3(gv), dim3(CS_NT), 0, s, x, partials, (long)rows, cols);    \
     } while (0)
         switch (tx) {
             case 32: CS_LAUNCH(32); break;
@@ -1012,13 +1021,34 @@ int calm_colsum(const void* x, float* out, int64_t rows, int32_t cols, int32_t x
         }
 #undef CS_LAUNCH
         CALM_LAUNCH_CHECK();
+        calm_reduce_partials(partials, gv, cols, out, s);
+        CALM_LAUNCH_CHECK();
         return 0;
     }
-    int g = cols >= NT ? (int)(rows < 512 ? rows : 512) : grid_for(rows * cols, NT * 8);
-    if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(colsum_kernel, dim3(g), dim3(NT), 0, as_stream(stream), x, out, (long)rows, cols, x_type);
+    const int g = colsum_grid(rows, cols, false, nullptr);
+    hipLaunchKernelGGL(colsum_kernel, dim3(g), dim3(NT), 0, s, x, partials, (long)rows, cols, x_type);
+    CALM_LAUNCH_CHECK();
+    calm_reduce_partials(partials, g, cols, out, s);
     CALM_LAUNCH_CHECK();
     return 0;
+}
+
+/* floats of `partials` scratch an entry point with a cross-workgroup reduction needs (upper bound over its kernel
+ * variants); op = CALM_RED_*; (rows, cols) as documented at the enum */
+int64_t calm_reduce_scratch_floats(int32_t op, int64_t rows, int32_t cols) {
+    if (rows <= 0 || cols <= 0) return 0;
+    switch (op) {
+        case CALM_RED_LAYERNORM_BWD: return (int64_t)ln_bwd_grid(rows) * cols;
+        case CALM_RED_ROPE_BWD: return (int64_t)4096 * (cols / 2);
+        case CALM_RED_LATENT_FWD: return latent_grid(rows, cols);
+        case CALM_RED_COLSUM: {
+            const int64_t a = (int64_t)colsum_grid(rows, cols, false, nullptr) * cols;
+            const int64_t b = (cols & 3) == 0 && rows >= 64 ? (int64_t)colsum_grid(rows, cols, true, nullptr) * cols : 0;
+            return a > b ? a : b;
+        }
+        case CALM_RED_CNN_BWD: return (int64_t)256 * 560;       // cnn_fused.hip: grid <= 256 rows of CNN_PART_STRIDE
+        default: return 0;
+    }
 }
 
 int calm_row_scale(const float* x, const float* s, void* out, int32_t rows, int32_t cols, int32_t out_type,

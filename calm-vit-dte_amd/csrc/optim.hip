@@ -114,9 +114,11 @@ __global__ __launch_bounds__(NT) void optim_finalize(const calm_optim_tensor* __
 
 __global__ __launch_bounds__(NT) void optim_update(const calm_optim_tensor* __restrict__ T, const int* __restrict__ chunk_tensor,
                                                    const float* __restrict__ stats, const Globals* __restrict__ G,
-                                                   calm_optim_hparams hp, const int* __restrict__ step_dev) {
+                                                   calm_optim_hparams hp, const int* __restrict__ step_dev,
+                                                   const float* __restrict__ lr_dev) {
     if (G->found_inf != 0.f) return;          // the reference's scaler.step() skips optimizer.step() on inf/NaN
     if (step_dev) hp.step = step_dev[0];      // already advanced by optim_finalize for this (un-skipped) step
+    if (lr_dev) hp.lr = lr_dev[0];            // a captured step follows the LR schedule through this device scalar
     const int t = chunk_tensor[blockIdx.x];
     const calm_optim_tensor e = T[t];
     const long i0 = (long)(blockIdx.x - e.chunk0) * CHUNK;
@@ -151,7 +153,7 @@ int32_t calm_optim_chunk_elems(void) { return CHUNK; }
 
 int calm_optim_step(const calm_optim_tensor* tensors_dev, int32_t n_tensors, const int32_t* chunk_tensor_dev,
                     int32_t n_chunks, float* scratch, const calm_optim_hparams* hp, const float* grad_scale,
-                    float* stats_out, int32_t* step_dev, void* stream) {
+                    float* stats_out, int32_t* step_dev, const float* lr_dev, void* stream) {
     if (!tensors_dev || !chunk_tensor_dev || !scratch || !hp || !stats_out || n_tensors <= 0 || n_chunks <= 0)
         return CALM_E_INVAL;
     if ((!step_dev && hp->step < 1) || hp->lr < 0.f || hp->beta1 < 0.f || hp->beta1 >= 1.f || hp->beta2 < 0.f || hp->beta2 >= 1.f)
@@ -168,7 +170,7 @@ int calm_optim_step(const calm_optim_tensor* tensors_dev, int32_t n_tensors, con
                        grad_scale, stats_out, (const float*)chunk_part, step_dev);
     CALM_LAUNCH_CHECK();
     hipLaunchKernelGGL(optim_update, dim3(n_chunks), dim3(NT), 0, s, tensors_dev, chunk_tensor_dev,
-                       (const float*)scratch, (const Globals*)G, *hp, (const int*)step_dev);
+                       (const float*)scratch, (const Globals*)G, *hp, (const int*)step_dev, lr_dev);
     CALM_LAUNCH_CHECK();
     return 0;
 }

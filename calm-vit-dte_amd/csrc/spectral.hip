@@ -172,11 +172,25 @@ __global__ __launch_bounds__(NT) void cast_one_kernel(const float* __restrict__ 
     for (long i = 8 * n8 + (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) dst[i] = (__bf16)src[i];
 }
 
+__global__ __launch_bounds__(NT) void cast_f32_kernel(const __bf16* __restrict__ src, float* __restrict__ dst, long n) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) dst[i] = (float)src[i];
+}
+
 }  // namespace
 
 extern "C" {
 
 int32_t calm_cast_chunk_elems(void) { return CAST_CHUNK; }
+
+int calm_cast_f32_one(const void* src, float* dst, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0) return CALM_E_INVAL;
+    long g = (n + NT - 1) / NT;
+    if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(cast_f32_kernel, dim3((int)g), dim3(NT), 0, as_stream(stream), reinterpret_cast<const __bf16*>(src), dst,
+                       (long)n);
+    CALM_LAUNCH_CHECK();
+    return 0;
+}
 
 int calm_cast_bf16_one(const float* src, void* dst, int64_t n, void* stream) {
     if (!src || !dst || n <= 0) return CALM_E_INVAL;

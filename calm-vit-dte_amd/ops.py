@@ -786,6 +786,33 @@ class AddFn(Function):
         return g, g
 
 
+class RowsToImageFn(Function):
+    """[B,S,3S] -> [B,3,S,S]: the inverse tokenisation (the image a bare `proj(img)` call hands back)."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, rows):
+        be = get_backend()
+        rows = _c(rows)
+        B, S, W = rows.shape
+        assert W == 3 * S, "token grid must be [B,S,3S]"
+        img = torch.empty(B, 3, S, S, dtype=rows.dtype, device=rows.device)
+        be.rows_to_image(rows, img, B, S)
+        ctx.dims = (B, S)
+        return img
+
+    @staticmethod
+    @once_differentiable
+    @_amp_bwd
+    def backward(ctx, g):
+        be = get_backend()
+        B, S = ctx.dims
+        g = _c(g)
+        rows = torch.empty(B, S, 3 * S, dtype=g.dtype, device=g.device)
+        be.image_to_rows(g, rows, B, S)
+        return rows
+
+
 class ImageToRowsFn(Function):
     """[B,3,S,S] -> [B,S,3S] (Vi_Tools:389-391)."""
 
@@ -872,14 +899,15 @@ class CnnResidualFn(Function):
 
     @staticmethod
     @_amp_fwd
-    def forward(ctx, x, w0, b0, w2, b2, w4, b4, u0, v0, s0, u2, v2, s2, u4, v4, s4):
+    def forward(ctx, x, w0, b0, w2, b2, w4, b4, u0, v0, s0, u2, v2, s2, u4, v4, s4, residual=True):
         be = get_backend()
         x = _c(x)
         B, S, W = x.shape
         Ch = w0.shape[0]
         out = torch.empty_like(x)
-        be.cnn_fwd(x, w0, s0, b0, w2, s2, b2, w4, s4, b4, out, B, S, Ch)
+        be.cnn_fwd(x, w0, s0, b0, w2, s2, b2, w4, s4, b4, out, B, S, Ch, residual=residual)
         ctx.dims = (B, S, Ch)
+        ctx.residual = residual
         ctx.defer = (_deferred(w0), _deferred(w2), _deferred(w4))
         ctx.save_for_backward(x, w0, b0, w2, b2, w4, b4, u0, v0, s0, u2, v2, s2, u4, v4, s4)
         return out
@@ -896,12 +924,39 @@ class CnnResidualFn(Function):
         dx = torch.empty_like(dy)
         gall = _zeros((Ch * 3 + Ch + Ch * 9 + Ch + 3 * Ch + 3,), dy)
         G0, db0, G2, db2, G4, db4 = torch.split(gall, [Ch * 3, Ch, Ch * 9, Ch, 3 * Ch, 3])
-        be.cnn_bwd(dy, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, dx, G0, db0, G2, db2, G4, db4, B, S, Ch)
+        be.cnn_bwd(dy, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, dx, G0, db0, G2, db2, G4, db4, B, S, Ch,
+                   residual=ctx.residual)
         dW0, _ = _sn_wbwd(be, G0.view(Ch, 3), w0.view(Ch, 3), u0, v0, s0, defer=ctx.defer[0])
         dW2, _ = _sn_wbwd(be, G2.view(Ch, 9), w2.view(Ch, 9), u2, v2, s2, defer=ctx.defer[1])
         dW4, _ = _sn_wbwd(be, G4.view(3, Ch), w4.view(3, Ch), u4, v4, s4, defer=ctx.defer[2])
         return (dx, dW0.view_as(w0), db0, dW2.view_as(w2), db2, dW4.view_as(w4), db4,
-                None, None, None, None, None, None, None, None, None)
+                None, None, None, None, None, None, None, None, None, None)
+
+
+class GeluFn(Function):
+    """erf-GELU on its own (the GELU module of a Sequential called directly; everywhere on the path the activation is
+    a GEMM epilogue or lives inside the fused CNN tail)."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, x):
+        be = get_backend()
+        x = _c(x)
+        y = torch.empty_like(x)
+        be.gelu_fwd(x, y, x.numel())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    @_amp_bwd
+    def backward(ctx, dy):
+        be = get_backend()
+        x, = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        be.gelu_bwd(dy, x, dx, x.numel())
+        return dx
 
 
 # ---------------------------------------------------------------------------------------

@@ -231,12 +231,15 @@ class TrainStep:
                 scale = sc.scale(self._one)                      # the current scale as a device tensor, no host sync
                 stats = self.opt.step(grad_scale=scale)
                 bad = stats[1] > 0
-                self._clean_steps = torch.where(bad, torch.zeros_like(self._clean_steps), self._clean_steps + 1)
+                # the counter is updated IN PLACE: a captured step (GraphedTrainStep) replays these kernels on the
+                # addresses seen at capture, so a rebound tensor would leave every replay reading the pre-capture value
+                # (the scale then never grows — or doubles on every replay from recycled memory)
+                self._clean_steps.copy_(torch.where(bad, torch.zeros_like(self._clean_steps), self._clean_steps + 1))
                 grow = self._clean_steps >= sc.get_growth_interval()
                 new_scale = torch.where(bad, scale * sc.get_backoff_factor(),
                                         torch.where(grow, scale * sc.get_growth_factor(), scale))
-                self._clean_steps = torch.where(grow, torch.zeros_like(self._clean_steps), self._clean_steps)
-                sc.update(new_scale.detach())
+                self._clean_steps.copy_(torch.where(grow, torch.zeros_like(self._clean_steps), self._clean_steps))
+                sc.update(new_scale.detach())          # GradScaler.update(tensor) copies into its scale tensor in place
             else:
                 self.opt.step()
             return loss.detach(), y_hat.detach()
@@ -432,6 +435,18 @@ class FusedClipAdamW(torch.optim.Optimizer):
         self._finalizer = weakref.finalize(self, _clear_deferred, [weakref.ref(p) for p in self._deferred], ops.DEFER_ATTR,
                                            self._token)
         self.stats = torch.zeros(2, dtype=torch.float32, device=self.params[0].device)   # [grad norm, found_inf]
+        # learning rate as a device scalar for captured steps (GraphedTrainStep sets lr_on_device and refreshes it from
+        # param_groups[0]["lr"] before a replay whenever a scheduler has changed it); eager steps pass the host value
+        self.lr_on_device = False
+        self._lr_dev = torch.full((1,), float(lr), dtype=torch.float32, device=self.params[0].device)
+        self._lr_dev_value = float(lr)
+
+    def sync_lr_to_device(self):
+        """Write param_groups[0]["lr"] to the device scalar a captured step reads (no-op when unchanged)."""
+        lr = float(self.lr)
+        if lr != self._lr_dev_value:
+            self._lr_dev.fill_(lr)
+            self._lr_dev_value = lr
 
     @property
     def step_count(self):
@@ -482,7 +497,9 @@ class FusedClipAdamW(torch.optim.Optimizer):
                 g = p.grad = g.contiguous()
             grads.append(g)
         hp = (float(self.lr), self.betas[0], self.betas[1], self.eps, self.weight_decay, self.max_norm or 0.0, 0)
-        self.be.optim_step(self._plan, grads, hp, grad_scale, self.stats)
+        if self.lr_on_device and not torch.cuda.is_current_stream_capturing():
+            self.sync_lr_to_device()
+        self.be.optim_step(self._plan, grads, hp, grad_scale, self.stats, lr_dev=self._lr_dev if self.lr_on_device else None)
         for p in self.params:
             p.grad = None
         return self.stats
@@ -514,12 +531,21 @@ class GraphedTrainStep:
     (the scale update is device arithmetic, see TrainStep._finish).  Removes the ~3000 host-side launches per step: the
     host's share of a step drops from tens of milliseconds to one graph launch, which is what keeps 8 ranks on one
     host from becoming host-bound.  Single-GPU in this revision: capturing the bucketed RCCL all-reduce on its side stream
-    was tried in a world of one (torch 2.10 + RCCL 2.26.6) and crashes inside the capture, so N > 1 runs eagerly.  Inputs are
-    copied into static buffers.  A learning-rate scheduler acts on replays only for optimizers that read the rate from
-    the device; FusedClipAdamW takes it as a launch argument, so re-capture after changing it."""
+    was tried in a world of one (torch 2.10 + RCCL 2.26.6) and crashes inside the capture, so N > 1 runs eagerly (the
+    constructor refuses a world of more than one rank).  Inputs are copied into static buffers.  A learning-rate
+    scheduler acts on replays: FusedClipAdamW reads the rate from a device scalar (calm_optim_step's lr_dev, ABI v7)
+    that __call__ refreshes from param_groups[0]["lr"] before the replay; capturable torch optimizers keep theirs on
+    the device already."""
 
     def __init__(self, model, optimizer, example_x, example_y, max_norm=1.0, warmup=3, scaler=None, autocast_dtype=None):
+        if dist.is_initialized() and dist.get_world_size() > 1:
+            # the captured step contains no gradient exchange: replicas would silently train apart (ADVICE r3)
+            raise RuntimeError("GraphedTrainStep captures a single-GPU step (no gradient all-reduce inside the graph); "
+                               "with world_size > 1 use TrainStep + BucketedGradReducer")
         self.inner = TrainStep(model, optimizer, None, max_norm=max_norm, scaler=scaler, autocast_dtype=autocast_dtype)
+        self.opt = optimizer
+        if isinstance(optimizer, FusedClipAdamW):
+            optimizer.lr_on_device = True          # replays read the learning rate from a device scalar
         self.x = example_x.clone()
         self.y = example_y.clone()
         side = torch.cuda.Stream()
@@ -536,6 +562,8 @@ class GraphedTrainStep:
     def __call__(self, x, y_soft):
         self.x.copy_(x, non_blocking=True)
         self.y.copy_(y_soft, non_blocking=True)
+        if isinstance(self.opt, FusedClipAdamW):
+            self.opt.sync_lr_to_device()           # a scheduler's new rate reaches the replay without re-capture
         self.graph.replay()
         return self.loss, self.y_hat
 
@@ -551,9 +579,29 @@ class SoftMixCollate:
     Host side, float images [B,3,H,W]; `DeviceCollate` is the uint8-on-device form of the same decisions."""
 
     def __init__(self, num_classes=1000, cutmix_alpha=1.0, mixup_alpha=0.8, seed=None):
-        import numpy as np
         self.num_classes, self.cutmix_alpha, self.mixup_alpha = num_classes, cutmix_alpha, mixup_alpha
-        self.rng = np.random.default_rng(seed)
+        self.seed = seed
+        self._rng = None
+        self._rng_worker = None
+
+    @property
+    def rng(self):
+        """The generator of THIS process: DataLoader workers each receive a pickled copy of the collate object, so a
+        generator built in __init__ would hand every worker the same (mode, lam, box) sequence.  It is
+        created on first use from (seed, worker id) — torchvision's transforms draw from the per-worker-seeded torch RNG
+        in the reference (num_workers=5, cls:62)."""
+        import numpy as np
+        info = torch.utils.data.get_worker_info()
+        wid = info.id if info is not None else -1
+        if self._rng is None or self._rng_worker != wid:
+            self._rng = np.random.default_rng(None if self.seed is None else [int(self.seed), wid + 1])
+            self._rng_worker = wid
+        return self._rng
+
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_rng"], st["_rng_worker"] = None, None        # never ship generator state to a worker
+        return st
 
     @staticmethod
     def cutmix_box(lam, cx, cy, H, W):
@@ -590,7 +638,7 @@ class SoftMixCollate:
 
 def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, epochs=15, batch_size=128,
           checkpoint_path=None, num_classes=1000, num_workers=0, collate_fn="mix", log_every=100, max_steps=None,
-          destroy_process_group=True):
+          destroy_process_group=True, device_collate=False, crop=None):
     """Per-rank training job: the reference's `train(initializer, optimizer, scheduler, use_gpu, dataset, epochs,
     batch_size)` (distributed_trainer_cls.py:25-114) on torch.distributed + RCCL instead of Spark's TorchDistributor —
     start one process per GPU with `python -m torch.distributed.run --nproc-per-node N ...` (RANK / LOCAL_RANK /
@@ -598,7 +646,8 @@ def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, ep
 
       * init_process_group (nccl on GPUs, gloo on CPU)                                   cls:46
       * CosineAnnealingLR(optimizer, T_max=epochs, eta_min=1e-6), stepped once per epoch  cls:52,108-109
-        (the reference builds it whatever `scheduler` it is handed; pass scheduler=False for a constant rate)
+        (scheduler=None / True: built here as the reference does — it builds this schedule whatever it is handed;
+        a scheduler OBJECT passed in is kept and stepped instead; scheduler=False: constant rate)
       * model.to(device); parameters + buffers broadcast from rank 0; gradients mean-all-reduced in buckets on a side
         stream (sync_module_states + BucketedGradReducer = what DDP(model) does)          cls:54-55
       * DistributedSampler(dataset, shuffle=True, seed=2006), set_epoch(epoch)           cls:56-57,73
@@ -609,7 +658,13 @@ def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, ep
 
     optimizer: a torch optimizer over `initializer.parameters()` (the reference hands in AdamW(lr=3.1e-3,
     weight_decay=0.02, betas=(0.9, 0.98))), or the string "fused" for FusedClipAdamW with those hyper-parameters (built
-    here, after the model is on its device).  checkpoint_path: the reference writes /config/Codebase/models/model_cls.pth."""
+    here, after the model is on its device).  checkpoint_path: the reference writes /config/Codebase/models/model_cls.pth.
+
+    device_collate=True: the dataset yields uint8 images [3,Hs,Ws] and integer labels; the DataLoader only
+    stacks them (default collate), the uint8 batch goes host-to-device as it is (a quarter of the fp32 bytes) and
+    `DeviceCollate` does ToDtype + Normalize + RandomCrop(crop) + flip + CutMix / MixUp in one kernel pass, writing the
+    first Block's row tokens [B,S,3S] directly — the model's first Block takes them without the image_to_rows pass
+    (cls:58-62,128-139; Vi_Tools:389-391)."""
     from torch.utils.data import DataLoader, DistributedSampler
     rank, local_rank, world = init_distributed(use_gpu)
     device = torch.device(f"cuda:{local_rank}" if use_gpu else "cpu")
@@ -629,7 +684,13 @@ def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, ep
     else:
         sampler = DistributedSampler(dataset, num_replicas=1, rank=0, shuffle=True, seed=2006)
     sampler.set_epoch(0)
-    if collate_fn == "mix":
+    dcoll = None
+    if device_collate:
+        if not use_gpu:
+            raise ValueError("device_collate=True needs use_gpu=True (the collate is a HIP kernel)")
+        dcoll = DeviceCollate(num_classes=num_classes, seed=2006 + rank)
+        collate_fn = None                                   # default_collate: stack uint8 images and labels
+    elif collate_fn == "mix":
         collate_fn = SoftMixCollate(num_classes=num_classes, seed=2006 + rank)
     loader = DataLoader(dataset, batch_size=batch_size, sampler=sampler, collate_fn=collate_fn, num_workers=num_workers,
                         pin_memory=use_gpu, persistent_workers=num_workers > 0)
@@ -645,6 +706,8 @@ def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, ep
             epoch_loss = 0.0
             for i, (x, y) in enumerate(loader):
                 x, y = x.to(device, non_blocking=True), y.to(device, non_blocking=True)
+                if dcoll is not None:
+                    x, y = dcoll(x, y.long(), crop=crop, tokens=True)   # uint8 batch -> row tokens + soft labels
                 loss, y_hat = step(x, y)
                 epoch_loss += loss.item()                                                                  # cls:97
                 if rank == 0 and local_rank == 0 and i % log_every == 0:

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define CALM_ABI_VERSION 6
+#define CALM_ABI_VERSION 7
 
 #define CALM_E_INVAL   (-1)   /* null pointer / negative size                 */
 #define CALM_E_LAYOUT  (-2)   /* stride pattern the kernel cannot address     */
@@ -135,15 +135,61 @@ int64_t calm_gemm_workspace_bytes(const calm_gemm_args* args);
  *                         (gemm_f32p_kernel) — 1: every eligible launch, 2: k-contiguous operand pairs only.  Off by
  *                         default: the fp32 matrix pipe is clock-limited under sustained load and both families end
  *                         at the same rate. */
+/*   CALM_GEMM_OPT_DETERMINISTIC (ABI v7) 0 (default; env CALM_GEMM_DETERMINISTIC): 1 = EVERY k-split / batch-reduced
+ *                         launch asks for a workspace (calm_gemm_workspace_bytes) and combines its slices through
+ *                         per-slice partial tiles and one fixed-order reduction pass — no fp32 atomics, the weight
+ *                         gradients repeat bit for bit (a launch that is handed no workspace still uses atomics).
+ *                         Off by default: below ~48 slices per output the atomics are faster (the partial tiles
+ *                         are written and read back once more).  The forward and input-gradient products never split:
+ *                         they are reproducible in either mode. */
 #define CALM_GEMM_OPT_PIPE   0
 #define CALM_GEMM_OPT_PIPE32 1
+#define CALM_GEMM_OPT_DETERMINISTIC 2
 int calm_gemm_set_option(int32_t option, int32_t value);
+
+/* ABI v7 — what calm_gemm would launch for `args` (nothing is enqueued): kernel family, tile, work decomposition.
+ * Diagnostic surface: tests use it to map a wrong output element back to (tile, persistent workgroup, XCD, wave,
+ * 16-row strip) — see tests/locate.py — and the bench to label its per-shape table.
+ *   family  0 fp32 128-row tiles (gemm_f32_kernel)        3 bf16 pipelined persistent (gemm_bf16p_kernel)
+ *           1 bf16-operand 128-row tiles                   4 fp32 pipelined persistent (gemm_f32p_kernel)
+ *           2 bf16-operand 256x128 tiles                   5 fp8
+ *   items = tiles_m * tiles_n * (batch entries or k-slices); the persistent families launch min(items, 256) workgroups
+ *   that walk items in the XCD-aware order of gemm_bf16p.h::decode, the others one workgroup per (tile, y). */
+typedef struct calm_gemm_plan {
+    int32_t family;
+    int32_t tile_m, tile_n, tile_k;
+    int32_t tiles_m, tiles_n;
+    int32_t k_slices;          /* k-slices per output (1: not split) */
+    int32_t items;
+    int32_t grid;              /* workgroups of the main launch */
+    int32_t epi_unit;          /* pipelined families: columns per lane of the row-layout epilogue (4 / 8); else 0 */
+    int32_t uses_workspace;    /* slices combined through args->workspace (1) or fp32 atomics (0) */
+    int32_t threads;           /* threads per workgroup */
+} calm_gemm_plan;
+int calm_gemm_describe(const calm_gemm_args* args, calm_gemm_plan* plan);
+
+/* ---------------------------------------------------------------------------------------
+ * ABI v7 — fixed-order cross-workgroup reductions.  Every entry point whose result sums over workgroups (LayerNorm dw,
+ * RoPE d_inv_freq, bias column sums, the latent KL sum, the CNN tail's weight gradients) takes `partials`: device
+ * scratch of at least calm_reduce_scratch_floats(op, rows, cols) floats (16-byte aligned).  Workgroup g writes one
+ * row of partial sums; a second launch of the same call adds the rows in workgroup order.  No atomics remain outside
+ * calm_gemm's optional k-split (CALM_GEMM_OPT_DETERMINISTIC) and the standalone calm_dwconv3x3_bwd helper: forward and
+ * backward of the path repeat bit for bit.  The scratch is only used until the call's kernels have run on `stream`.
+ *   op                        rows                 cols
+ *   CALM_RED_LAYERNORM_BWD    rows                 D
+ *   CALM_RED_ROPE_BWD         B*S*H                dr
+ *   CALM_RED_LATENT_FWD       rows                 mvh
+ *   CALM_RED_COLSUM           rows                 cols
+ *   CALM_RED_CNN_BWD          B                    S
+ * ------------------------------------------------------------------------------------- */
+enum { CALM_RED_LAYERNORM_BWD = 0, CALM_RED_ROPE_BWD = 1, CALM_RED_LATENT_FWD = 2, CALM_RED_COLSUM = 3, CALM_RED_CNN_BWD = 4 };
+int64_t calm_reduce_scratch_floats(int32_t op, int64_t rows, int32_t cols);
 
 /* ---------------------------------------------------------------------------------------
  * LayerNorm(D, eps, bias=False) over the last axis (Vi_Tools:131-132,197,494; fwd 211-215,311,523).
  * x,y: [rows, D] contiguous.  mean,rstd: [rows] saved for backward.
  * bwd: dx = rstd*(w*dy - mean_D(w*dy) - xhat*mean_D(w*dy*xhat)) [+ dx_add]; dw[D] += sum_rows dy*xhat
- * (dw must be zeroed by the caller; accumulated with atomics).  dx_add (nullable, x's layout): gradient arriving
+ * (added onto the caller's dw in a fixed order through `partials`, see calm_reduce_scratch_floats).  dx_add (nullable, x's layout): gradient arriving
  * through the skip connection that bypasses the norm (x feeds LN and the block's residual add, Vi_Tools:209-211,
  * 309-315), summed into dx here instead of by a separate elementwise pass.
  * y_type / dy_type (CALM_ST_*, ABI v4): the normalised output and the gradient arriving for it may be bf16 tensors
@@ -153,7 +199,7 @@ int calm_layernorm_fwd(const float* x, const float* w, void* y, float* mean, flo
                        int64_t rows, int32_t D, float eps, int32_t y_type, void* stream);
 int calm_layernorm_bwd(const void* dy, const float* x, const float* w, const float* mean,
                        const float* rstd, float* dx, float* dw, const float* dx_add, int64_t rows, int32_t D,
-                       int32_t dy_type, void* stream);
+                       int32_t dy_type, float* partials /* ABI v7 */, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Learned-frequency NeoX RoPE + head assembly (Vi_Tools:80-95 applied at 275-285).
@@ -162,7 +208,8 @@ int calm_layernorm_bwd(const void* dy, const float* x, const float* w, const flo
  * content: [B,S,H,dc], xr: [B,S,H,dr], out: [B,S,H,dc+dr], all contiguous.
  * table: [2, S, dr/2] workspace; fwd fills it with cos|sin(t * inv_freq) (rebuilt every forward
  * because inv_freq is a learned parameter, Vi_Tools:70-71,86-91) and bwd reads it back.
- * bwd: d_content, d_xr from d_out; d_inv_freq[dr/2] += ... (atomics; caller zeroes).
+ * bwd: d_content, d_xr from d_out; d_inv_freq[dr/2] += ... (fixed order through `partials`; dr/2 <= 256 and tensors
+ * below 2^31 elements, CALM_E_UNSUPP otherwise).
  * Each tensor may be fp32 or bf16 (type arguments): in the bf16 pipeline the projections write bf16 and the
  * attention reads bf16 q / k; the rotation itself, the table and d_inv_freq are fp32.
  * ------------------------------------------------------------------------------------- */
@@ -172,7 +219,8 @@ int calm_rope_fwd(const void* content, const void* xr, const float* inv_freq, fl
 int calm_rope_bwd(const void* d_out, const void* xr, const float* table,
                   void* d_content, void* d_xr, float* d_inv_freq,
                   int32_t B, int32_t S, int32_t H, int32_t dc, int32_t dr,
-                  int32_t dout_type, int32_t xr_type, int32_t dcontent_type, int32_t dxr_type, void* stream);
+                  int32_t dout_type, int32_t xr_type, int32_t dcontent_type, int32_t dxr_type,
+                  float* partials /* ABI v7 */, void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Row softmax of the masked logits and its backward (the softmax inside
@@ -242,12 +290,12 @@ int calm_attention16_bwd(const void* q, const void* k, const void* v, const void
 /* ---------------------------------------------------------------------------------------
  * Latent bottleneck sampling (Vi_Tools:232-242) + KL partial sum (Vi_Tools:24-25).
  * mv: [rows, 2*mvh] (mean | raw).  std = softplus(raw)+1e-6;  z = mean + noise*std (noise NULL
- * in eval: z = mean).  kl_sum (device scalar, caller zeroes) += sum(1 + 2 log std - mean^2 - std^2) — block partials
- * combined with fp32 atomics: the last bit of kl_sum is not reproducible between runs (z and std are).
+ * in eval: z = mean).  kl_sum (device scalar) += sum(1 + 2 log std - mean^2 - std^2) — block partials through
+ * `partials`, added in block order (ABI v7: reproducible; rounds 1-3 used fp32 atomics).
  * bwd: dmv from dz and the scalar d(kl_sum) (device pointer).
  * ------------------------------------------------------------------------------------- */
 int calm_latent_fwd(const float* mv, const float* noise, float* z, float* std_out, float* kl_sum,
-                    int64_t rows, int32_t mvh, void* stream);
+                    int64_t rows, int32_t mvh, float* partials /* ABI v7 */, void* stream);
 int calm_latent_bwd(const float* dz, const float* d_kl_sum, const float* mv, const float* noise,
                     const float* std_in, float* dmv, int64_t rows, int32_t mvh, void* stream);
 
@@ -309,6 +357,9 @@ int calm_quantize_fp8(const void* x, int32_t x_type, int64_t n, void* q, int32_t
 int calm_transpose_u8(const void* in, void* out, int32_t rows, int32_t cols, void* stream);
 /* one tensor: dst[i] = bf16(src[i]) — the fp32 residual-stream gradient that two backward GEMMs are about to read */
 int calm_cast_bf16_one(const float* src, void* dst, int64_t n, void* stream);
+/* ABI v7 — dst[i] = (float)src[i] for a bf16 tensor: the fp32 copies of the rare bf16 launch whose strides rule out
+ * 16-byte staging (10-class head, 36-token stage of the fixture models) — rounds 1-3 used torch casts there */
+int calm_cast_f32_one(const void* src, float* dst, int64_t n, void* stream);
 
 /* Weight gradient through W = W_orig / sigma (and an optional LayerScale on the output):
  *   d_ls[c]  = sum_k G[c,k] * W_orig[c,k] / sigma            (only if ls != NULL; written)
@@ -359,6 +410,8 @@ int32_t calm_optim_chunk_elems(void);
 int calm_optim_step(const calm_optim_tensor* tensors_dev, int32_t n_tensors, const int32_t* chunk_tensor_dev,
                     int32_t n_chunks, float* scratch, const calm_optim_hparams* hparams,
                     const float* grad_scale /* device scalar or NULL */, float* stats_out, int32_t* step_dev,
+                    const float* lr_dev /* ABI v7: device scalar overriding hparams->lr, or NULL — lets a captured
+                                           (hipGraph) step follow an LR schedule without re-capture */,
                     void* stream);
 
 /* ---------------------------------------------------------------------------------------
@@ -394,7 +447,8 @@ int calm_grid_transpose(const float* in, float* out, int32_t B, int32_t S, void*
  * Depthwise 3x3 conv (padding 1, zeros) + bias on a channels-last [B,S,S,C] grid
  * (middle layer of Block.proj, Vi_Tools:382; CALM_ViT_V2.py:64).  w: [C,3,3], bias: [C].
  * act: CALM_ACT_NONE/GELU; y_pre (optional) receives the pre-activation.
- * bwd: dx from dz (gradient wrt the pre-activation); dw[C,9], db[C] accumulated (caller zeroes).
+ * bwd: dx from dz (gradient wrt the pre-activation); dw[C,9], db[C] accumulated (caller zeroes; fp32 atomics —
+ * a standalone helper, the path runs the convolutions fused in calm_cnn_residual_*).
  * ------------------------------------------------------------------------------------- */
 int calm_dwconv3x3_fwd(const float* x, const float* w, const float* inv_scale, const float* bias,
                        float* y, float* y_pre, int32_t act, int32_t B, int32_t S, int32_t C, void* stream);
@@ -405,29 +459,34 @@ int calm_dwconv3x3_bwd(const float* dz, const float* x, const float* w, const fl
  * Fused CNN residual of Block.proj / ViT.proj (Vi_Tools:378-385,400-403; CALM_ViT_V2.py:60-67,80-83):
  *   out = x + conv1x1_{hidden->3}(gelu(dwconv3x3(gelu(conv1x1_{3->hidden}(x)))))   on [B,S,S,3] tokens.
  * w0:[hidden,3] w2:[hidden,9] w4:[3,hidden] are the *_orig weights, s0/s2/s4 their device sigmas.
- * The hidden maps stay in LDS per 16x16 tile; backward recomputes them.  bwd writes dx and ACCUMULATES
- * (atomics; caller zeroes) the gradients wrt the effective weights W/sigma (g0,g2,g4) and biases.
- * hidden must be 32.
+ * The hidden maps stay in LDS per 16x16 tile; backward recomputes them.  bwd writes dx and ADDS (fixed order through
+ * `partials`) the gradients wrt the effective weights W/sigma (g0,g2,g4) and biases onto the caller's tensors.
+ * hidden must be 32.  residual (ABI v7): 1 = the form above (Block.forward / ViT.forward, Vi_Tools:400-403); 0 = the bare
+ * `proj(x)` a caller of the reference may invoke on its own (out = conv(...), dx without the skip term).
  * ------------------------------------------------------------------------------------- */
 int calm_cnn_residual_fwd(const float* x, const float* w0, const float* s0, const float* b0, const float* w2,
                           const float* s2, const float* b2, const float* w4, const float* s4, const float* b4,
-                          float* out, int32_t B, int32_t S, int32_t hidden, void* stream);
+                          float* out, int32_t B, int32_t S, int32_t hidden, int32_t residual, void* stream);
 int calm_cnn_residual_bwd(const float* dy, const float* x, const float* w0, const float* s0, const float* b0,
                           const float* w2, const float* s2, const float* b2, const float* w4, const float* s4,
                           const float* b4, float* dx, float* g0, float* gb0, float* g2, float* gb2, float* g4,
-                          float* gb4, int32_t B, int32_t S, int32_t hidden, void* stream);
+                          float* gb4, int32_t B, int32_t S, int32_t hidden, int32_t residual, float* partials,
+                          void* stream);
 
 /* ---------------------------------------------------------------------------------------
  * Small streaming helpers.
  * add          : out = a + b                         (residual / U-net skips, Vi_Tools:309,315,403,513-522)
+ * gelu_fwd     : y = gelu_erf(x)                     (ABI v7: the GELU module called on its own; fused everywhere else)
  * gelu_bwd     : dz = dy * gelu'(z)                  (where it is not fused into a GEMM epilogue)
- * colsum       : out[n] += sum_m x[m,n]              (bias gradients; caller zeroes)
+ * colsum       : out[n] += sum_m x[m,n]              (bias gradients; fixed order through `partials`)
  * row_scale    : out[r,c] = x[r,c] * s[r]            (ls-scaled weight for the dgrad of out_proj/mlp.3; fp32 or bf16 out)
  * mean_seq     : y[b,d] = mean_s x[b,s,d]            (AdaptiveAvgPool1d, CALM_ViT_V2.py:74-75) and bwd
  * ------------------------------------------------------------------------------------- */
 int calm_add(const float* a, const float* b, float* out, int64_t n, void* stream);
+int calm_gelu_fwd(const float* x, float* y, int64_t n, void* stream);
 int calm_gelu_bwd(const float* dy, const float* z, float* dz, int64_t n, void* stream);
-int calm_colsum(const void* x, float* out, int64_t rows, int32_t cols, int32_t x_type /* CALM_ST_* */, void* stream);
+int calm_colsum(const void* x, float* out, int64_t rows, int32_t cols, int32_t x_type /* CALM_ST_* */,
+                float* partials /* ABI v7 */, void* stream);
 int calm_row_scale(const float* x, const float* s, void* out, int32_t rows, int32_t cols, int32_t out_type /* CALM_ST_* */,
                    void* stream);
 int calm_mean_seq_fwd(const float* x, float* y, int32_t B, int32_t S, int32_t D, void* stream);

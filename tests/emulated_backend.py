@@ -163,10 +163,12 @@ class EmulatedBackend:
         plan.param_ptrs = np.asarray([r["param"].data_ptr() for r in records], dtype=np.uint64)
         return plan
 
-    def optim_step(self, plan, grads, hp, grad_scale, stats_out):
+    def optim_step(self, plan, grads, hp, grad_scale, stats_out, lr_dev=None):
         """calm_optim_step: deferred spectral-norm correction, global norm, clip, torch.optim.AdamW's update; the step
         count lives in plan.step_dev and does not advance on a skipped (inf/NaN) step."""
         lr, b1, b2, eps, wd, max_norm, _ = hp
+        if lr_dev is not None:
+            lr = float(lr_dev[0])
         plan, step_dev = plan.records, plan.step_dev
         fixed = []
         for r, g in zip(plan, grads):
@@ -437,25 +439,26 @@ class EmulatedBackend:
         db.add_(dz.view(-1, Cch).sum(dim=0))
 
     @staticmethod
-    def _cnn(x, w0, s0, b0, w2, s2, b2, w4, s4, b4, B, S, hidden):
+    def _cnn(x, w0, s0, b0, w2, s2, b2, w4, s4, b4, B, S, hidden, residual=True):
         F = torch.nn.functional
         img = x.view(B, S, S, 3).permute(0, 3, 1, 2)
         h = _gelu(F.conv2d(img, (w0 / s0).view(hidden, 3, 1, 1), b0))
         h = _gelu(F.conv2d(h, (w2 / s2).view(hidden, 1, 3, 3), b2, padding=1, groups=hidden))
         h = F.conv2d(h, (w4 / s4).view(3, hidden, 1, 1), b4)
-        return (img + h).permute(0, 2, 3, 1).reshape(B, S, 3 * S)
+        return ((img + h) if residual else h).permute(0, 2, 3, 1).reshape(B, S, 3 * S)
 
-    def cnn_fwd(self, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, out, B, S, hidden):
-        out.copy_(self._cnn(x, w0, s0, b0, w2, s2, b2, w4, s4, b4, B, S, hidden))
+    def cnn_fwd(self, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, out, B, S, hidden, residual=True):
+        out.copy_(self._cnn(x, w0, s0, b0, w2, s2, b2, w4, s4, b4, B, S, hidden, residual))
 
-    def cnn_bwd(self, dy, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, dx, g0, gb0, g2, gb2, g4, gb4, B, S, hidden):
+    def cnn_bwd(self, dy, x, w0, s0, b0, w2, s2, b2, w4, s4, b4, dx, g0, gb0, g2, gb2, g4, gb4, B, S, hidden,
+                residual=True):
         leaf = lambda t: t.detach().clone().requires_grad_(True)
         xl = leaf(x)
         e0, e2, e4 = leaf(w0.reshape(hidden, 3) / s0), leaf(w2.reshape(hidden, 9) / s2), leaf(w4.reshape(3, hidden) / s4)
         c0, c2, c4 = leaf(b0), leaf(b2), leaf(b4)
         one = torch.ones(1, device=x.device)
         with torch.enable_grad():
-            y = self._cnn(xl, e0, one, c0, e2, one, c2, e4, one, c4, B, S, hidden)
+            y = self._cnn(xl, e0, one, c0, e2, one, c2, e4, one, c4, B, S, hidden, residual)
             gr = torch.autograd.grad(y, (xl, e0, c0, e2, c2, e4, c4), dy.reshape(B, S, 3 * S))
         dx.copy_(gr[0].reshape(dx.shape))
         g0.view(hidden, 3).add_(gr[1]); gb0.add_(gr[2]); g2.view(hidden, 9).add_(gr[3]); gb2.add_(gr[4])
@@ -463,6 +466,9 @@ class EmulatedBackend:
 
     def add(self, a, b, out, n):
         out.copy_(a + b)
+
+    def gelu_fwd(self, x, y, n):
+        y.copy_(_gelu(x))
 
     def gelu_bwd(self, dy, z, dz, n):
         dz.copy_(dy * _gelu_grad(z))
