@@ -10,6 +10,7 @@ import torch
 import calm_vit_dte_amd as calm
 from emulated_backend import EmulatedBackend
 from helpers import rel_err
+from locate import check_gemm, item_of_linear
 
 pytestmark = pytest.mark.gpu
 
@@ -72,9 +73,14 @@ def test_pipelined_gemm_against_emulation(M, N, K, batch, akc, bkc, epi):
     C_ref = torch.zeros(b0, b1, M, N, dtype=cdt)
     C_hip = torch.full((b0, b1, M, N), 7.0, dtype=cdt).cuda()
     emu.gemm(A, B, C_ref, M, N, K, a, b, c, batch=batch, **kw)
-    hip.gemm(A.cuda(), B.cuda(), C_hip, M, N, K, a, b, c, batch=batch, **kw_hip)
+    args, kwa = (A.cuda(), B.cuda(), C_hip, M, N, K, a, b, c), dict(batch=batch, **kw_hip)
+    hip.gemm(*args, **kwa)
     assert torch.isfinite(C_hip.float()).all()
-    assert rel_err(C_hip.float(), C_ref.float()) < tol * max(1.0, (K / 1024) ** 0.5)
+    bound = tol * max(1.0, (K / 1024) ** 0.5)
+    if batch == (1, 1):          # self-locating on a violation (tests/locate.py): tile / workgroup slot / XCD / wave / strip
+        check_gemm(f"pipe_{M}x{N}x{K}_{int(akc)}{int(bkc)}_{epi}", hip, C_hip[0, 0], C_ref[0, 0].cuda(), bound, args, kwa,
+                   cross_family=False)
+    assert rel_err(C_hip.float(), C_ref.float()) < bound
     if cdt == torch.bfloat16:
         assert (C_hip.cpu() == C_ref).float().mean() > 0.97
 
@@ -134,3 +140,38 @@ def test_pipelined_gemm_propagates_nan_and_ignores_padding():
     hip.gemm(A, B, C, M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0), split_k=1)
     bad = torch.isnan(C)
     assert bad[17].all() and int(bad.sum()) == N
+
+
+def test_describe_reports_the_launch_decomposition_and_the_item_order_inverts():
+    """calm_gemm_describe (ABI v7): the plan of the bench-size GELU' data gradient is the pipelined family on 256 x 224
+    tiles, 1344 items on 256 persistent workgroups; tests/locate.py's inverse of the XCD-aware item order is a bijection
+    whose items with equal index mod 8 are consecutive tiles (gemm_bf16p.h::decode)."""
+    hip = calm.backend.get_backend()
+    M, N = 57344, 1344
+    dy = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    w = torch.empty(N, N, dtype=torch.bfloat16, device="cuda")
+    plan = hip.gemm_describe(dy, w, torch.empty_like(dy), M, N, N, (N, 1, 0, 0), (1, N, 0, 0), (N, 0, 0), act=2, aux=dy,
+                             split_k=1)
+    assert plan["family"] == 3 and (plan["tile_m"], plan["tile_n"]) == (256, 224)
+    assert plan["items"] == 224 * 6 and plan["grid"] == 256 and plan["epi_unit"] == 8 and plan["k_slices"] == 1
+    for n_items in (5, 8, 13, 1344, 1345, 1351):
+        items = [item_of_linear(lin, n_items) for lin in range(n_items)]
+        assert sorted(items) == list(range(n_items))
+        if n_items >= 8:
+            by_x = {}
+            for lin, it in enumerate(items):
+                by_x.setdefault(it % 8, []).append(lin)
+            assert all(v == list(range(v[0], v[0] + len(v))) for v in by_x.values())
+    # a weight gradient: k-split, and with the deterministic option every split launch asks for a workspace
+    x = torch.empty(M, 672, dtype=torch.bfloat16, device="cuda")
+    G = torch.empty(N, 672, device="cuda")
+    wg = (dy, x, G, N, 672, M, (1, N, 0, 0), (1, 672, 0, 0), (672, 0, 0))
+    p0 = hip.gemm_describe(*wg)
+    assert p0["k_slices"] > 1
+    prev = hip.gemm_set_option(hip.GEMM_OPT_DETERMINISTIC, 1)
+    try:
+        g, _ = hip._gemm_args(*wg)
+        import ctypes
+        assert hip.lib.calm_gemm_workspace_bytes(ctypes.byref(g)) == 4 * p0["k_slices"] * N * 672
+    finally:
+        hip.gemm_set_option(hip.GEMM_OPT_DETERMINISTIC, prev)

@@ -125,9 +125,9 @@ def test_checkpoint_round_trip(tmp_path):
     m2 = m2.cuda().eval()
     with torch.no_grad():
         y1, kl1 = m2(x.cuda())
-    # the logits repeat bit for bit; the KL sum is combined over blocks with fp32 atomics (calm_latent_fwd), whose order
-    # — hence last bit — is not fixed (it feeds no weight: its gradient does not depend on its value)
-    assert torch.equal(y0, y1) and abs(float(kl0) - float(kl1)) <= 2e-6 * abs(float(kl0))
+    # logits AND the KL sum repeat bit for bit (ABI v7: calm_latent_fwd combines its block partials in block order;
+    # rounds 1-3 used fp32 atomics there and this check had to allow 2e-6)
+    assert torch.equal(y0, y1) and float(kl0) == float(kl1)
 
 
 def _one_step(name, fused, steps=2):
@@ -488,6 +488,8 @@ def test_bucketed_reducer_on_rccl_world_of_one_is_bit_identical_to_no_reducer():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0,
                             device_id=torch.device("cuda", 0))
+    be = calm.backend.get_backend()
+    prev_det = be.gemm_set_option(be.GEMM_OPT_DETERMINISTIC, 1)
     try:
         assert dist.get_backend() == "nccl"
         name = "nano48_cls"
@@ -510,11 +512,12 @@ def test_bucketed_reducer_on_rccl_world_of_one_is_bit_identical_to_no_reducer():
             torch.cuda.synchronize()
             results.append((losses, {k: v.clone() for k, v in m.state_dict().items()}))
         (l0, sd0), (l1, sd1) = results
-        # (the backward itself is not bit-reproducible run to run — LayerNorm / RoPE weight gradients are atomic sums —
-        # so the two trainings agree to rounding; the exchange itself is checked for exactness below)
-        assert all(abs(a - b) <= 2e-6 * max(1.0, abs(a)) for a, b in zip(l0, l1)), (l0, l1)
-        for k in sd0:
-            assert rel_err(sd1[k].float(), sd0[k].float()) < 3e-4, k   # AdamW's 1/sqrt(v) amplifies the atomic-sum noise
+        # ABI v7: the backward has no atomics left (fixed-order cross-workgroup reductions; k-split weight gradients through
+        # the workspace in deterministic mode), so the two trainings agree in EVERY bit — round 3 had to widen this to
+        # 3e-4 because LayerNorm / RoPE / batch-reduced weight gradients were atomic sums
+        assert l0 == l1, (l0, l1)
+        differing = [k for k in sd0 if not torch.equal(sd0[k], sd1[k])]
+        assert not differing, differing[:8]
         # the exchange alone, bit for bit: known gradients through the hooks -> buckets -> RCCL AVG -> bucket views
         lin = torch.nn.Sequential(torch.nn.Linear(300, 500), torch.nn.Linear(500, 700), torch.nn.Linear(700, 10)).cuda()
         red = trainer.BucketedGradReducer(lin, bucket_mb=1, tail_mb=1, force=True)
@@ -541,6 +544,7 @@ def test_bucketed_reducer_on_rccl_world_of_one_is_bit_identical_to_no_reducer():
         torch.cuda.current_stream().wait_stream(side)
         assert float(t[12345]) == 12345.0
     finally:
+        be.gemm_set_option(be.GEMM_OPT_DETERMINISTIC, prev_det)
         dist.destroy_process_group()
 
 
@@ -573,3 +577,74 @@ def test_graph_captured_step_with_the_fused_optimizer_and_grad_scaler_equals_eag
     assert all(abs(a - b) < 2e-2 * max(1.0, abs(a)) for a, b in zip(l_e, l_g)), (l_e, l_g)     # bf16 pipeline + atomics
     worst = max(rel_err(sd_g[k].float(), sd_e[k].float()) for k in sd_e)
     assert worst < 5e-2, worst
+
+
+def _scaled_run(graphed, xs, y, growth_interval, lrs=None):
+    """Steps of the reference call pattern (autocast + GradScaler + fused optimizer) over the inputs xs; returns the scale
+    after every step, the losses and the final state."""
+    name = "tiny32_cls"
+    g = load_golden(name)
+    m = build_model(name, g, "cuda").train()
+    opt = trainer.FusedClipAdamW(m)
+    scaler = torch.amp.GradScaler("cuda", init_scale=256.0, growth_interval=growth_interval)
+    scales, losses = [], []
+    try:
+        if graphed:
+            step = trainer.GraphedTrainStep(m, opt, xs[0], y, warmup=1, scaler=scaler, autocast_dtype=torch.bfloat16)
+        else:
+            step = trainer.TrainStep(m, opt, None, scaler=scaler, autocast_dtype=torch.bfloat16)
+            step(xs[0], y)                                # the graphed run's warm-up step
+        scales.append(scaler.get_scale())
+        for i, x in enumerate(xs):
+            if lrs is not None:
+                opt.param_groups[0]["lr"] = lrs[i]        # what a scheduler's step() does
+            losses.append(float(step(x, y)[0]))
+            scales.append(scaler.get_scale())
+        torch.cuda.synchronize()
+        steps = opt.step_count
+    finally:
+        opt.close()
+    return scales, losses, steps, {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
+def test_graphed_grad_scaler_grows_backs_off_and_skips_like_the_eager_one():
+    """the clean-step counter of the device-side GradScaler emulation must live at one address —
+    a captured step replays the kernels recorded at capture.  growth_interval = 2 makes the scale grow several times
+    within the run, and a batch with an inf in it forces a skipped step and a back-off in the middle: the scale after
+    every step is the eager run's, and so is the number of un-skipped optimizer steps."""
+    _, x, y = _batch("tiny32_cls", bs=8)
+    x, y = x.cuda(), y.cuda()
+    bad = x.clone()
+    bad[0, 0, 0, 0] = float("inf")
+    xs = [x, x, x, bad, x, x, x, x]
+    sc_e, _, steps_e, _ = _scaled_run(False, xs, y, growth_interval=2)
+    sc_g, _, steps_g, _ = _scaled_run(True, xs, y, growth_interval=2)
+    assert sc_e == sc_g, (sc_e, sc_g)
+    assert max(sc_e) > 256.0 and sc_e[4] < sc_e[3]       # it grew, and the inf batch halved it
+    assert steps_e == steps_g == len(xs)                 # 1 warm-up + 8 steps - 1 skipped
+
+
+def test_graphed_step_follows_a_learning_rate_schedule_without_recapture():
+    """FusedClipAdamW's learning rate reaches a captured step through a device scalar
+    (calm_optim_step lr_dev, ABI v7), so CosineAnnealingLR-style changes between replays act as in the eager run."""
+    _, x, y = _batch("tiny32_cls", bs=8)
+    x, y = x.cuda(), y.cuda()
+    lrs = [3.1e-3, 3.1e-3, 1.0e-3, 1.0e-3, 2.0e-4, 1.0e-6]
+    _, l_e, _, sd_e = _scaled_run(False, [x] * len(lrs), y, growth_interval=2000, lrs=lrs)
+    _, l_g, _, sd_g = _scaled_run(True, [x] * len(lrs), y, growth_interval=2000, lrs=lrs)
+    _, l_c, _, sd_c = _scaled_run(True, [x] * len(lrs), y, growth_interval=2000, lrs=[3.1e-3] * len(lrs))
+    worst = max(rel_err(sd_g[k].float(), sd_e[k].float()) for k in sd_e)
+    moved = max(rel_err(sd_c[k].float(), sd_e[k].float()) for k in sd_e)
+    assert worst < 5e-2, worst                           # bf16 pipeline: same bound as the graph-vs-eager test above
+    assert moved > 4 * worst, (moved, worst)             # a constant rate ends somewhere else: the schedule did act
+
+
+def test_graphed_step_refuses_a_world_of_more_than_one_rank(monkeypatch):
+    import torch.distributed as dist
+    monkeypatch.setattr(dist, "is_initialized", lambda: True)
+    monkeypatch.setattr(dist, "get_world_size", lambda *a, **k: 2)
+    name = "tiny32_cls"
+    m = build_model(name, load_golden(name), "cuda").train()
+    _, x, y = _batch(name, bs=2)
+    with pytest.raises(RuntimeError, match="single-GPU"):
+        trainer.GraphedTrainStep(m, trainer.make_optimizer(m, capturable=True), x.cuda(), y.cuda())
