@@ -468,10 +468,16 @@ __global__ __launch_bounds__(256) void mask_transpose_kernel(const __bf16* __res
 }
 
 #include "attention_bf16_fwd2.h"
+#include "attention_bf16_fwd3.h"
 
 // CALM_ATTN16_V2=0 in the environment: the register-staged forward for every shape (A/B runs)
 inline bool fwd2_enabled() {
     static const int on = [] { const char* e = getenv("CALM_ATTN16_V2"); return (e && e[0] == '0') ? 0 : 1; }();
+    return on != 0;
+}
+// CALM_ATTN16_V3=0: the head loop stays inside attn16_fwd2_kernel (A/B runs); default: mask kernel + per-head core kernel
+inline bool fwd3_enabled() {
+    static const int on = [] { const char* e = getenv("CALM_ATTN16_V3"); return (e && e[0] == '0') ? 0 : 1; }();
     return on != 0;
 }
 
@@ -487,6 +493,34 @@ int launch_fwd16_t(const Attn16P& p, size_t lds, hipStream_t s) {
             const int tiles2 = (p.S + 15) / 16;
             Attn16P p2 = p;
             p2.groups = (tiles2 + nw2 - 1) / nw2;
+            if constexpr (Fwd3Geo<NP, HDP>::OK) {
+                if (fwd3_enabled()) {
+                    // phases 1-2 (R, mask MLP -> Mk), then one workgroup per (image, head) for the head loop
+                    e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn16_fwd2_kernel<NP, HDP, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds2);
+                    if (e2 != hipSuccess) return (int)e2;
+                    constexpr int lds3 = Fwd3Geo<NP, HDP>::LDS;
+                    e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn16_fwd3_core_kernel<NP, HDP, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+                    if (e2 != hipSuccess) return (int)e2;
+                    e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn16_fwd3_core_kernel<NP, HDP, false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, lds3);
+                    if (e2 != hipSuccess) return (int)e2;
+                    hipLaunchKernelGGL((attn16_fwd2_kernel<NP, HDP, true>), dim3(p2.groups * p.B), dim3(64 * nw2), lds2, s, p2);
+                    CALM_LAUNCH_CHECK();
+                    static const int stagger = [] { const char* e = getenv("CALM_ATTN16_STAGGER"); return e ? atoi(e) : 0; }();
+                    p2.kv_shared = stagger;                  // (the core kernel's start offset of the odd wave slots, x 64 cycles)
+                    if (p.S == 32 * NP)
+                        hipLaunchKernelGGL((attn16_fwd3_core_kernel<NP, HDP, true>), dim3(p.B * p.H), dim3(256), lds3, s, p2);
+                    else
+                        hipLaunchKernelGGL((attn16_fwd3_core_kernel<NP, HDP, false>), dim3(p.B * p.H), dim3(256), lds3, s, p2);
+                    CALM_LAUNCH_CHECK();
+                    const int t32c = (p.S + 31) / 32;
+                    hipLaunchKernelGGL(mask_transpose_kernel, dim3(t32c, t32c, p.B), dim3(256), 0, s, (const __bf16*)p.Mk, p.MkT, p.S);
+                    CALM_LAUNCH_CHECK();
+                    return 0;
+                }
+            }
             hipLaunchKernelGGL((attn16_fwd2_kernel<NP, HDP>), dim3(p2.groups * p.B), dim3(64 * nw2), lds2, s, p2);
             CALM_LAUNCH_CHECK();
             const int t32b = (p.S + 31) / 32;

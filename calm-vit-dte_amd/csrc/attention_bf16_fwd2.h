@@ -139,7 +139,9 @@ struct Fwd2Geo {
 #define F2_ADD(acc, a, b)
 #endif
 
-template <int NP, int HDP>
+// MASK_ONLY (round 4): phases 1 and 2 alone — R, the hidden states and the mask M are written out and the kernel ends;
+// the per-head core then runs as attn16_fwd3_core_kernel (attention_bf16_fwd3.h), one workgroup per (image, head).
+template <int NP, int HDP, bool MASK_ONLY = false>
 __global__ __launch_bounds__(64 * waves_for(NP), 2) void attn16_fwd2_kernel(const Attn16P p) {
     typedef Fwd2Geo<NP, HDP> G;
     constexpr int NJ = 2 * NP, SP = G::SP, NW = G::NW;
@@ -432,6 +434,22 @@ __global__ __launch_bounds__(64 * waves_for(NP), 2) void attn16_fwd2_kernel(cons
 #ifdef ATT16_STAMP
     const unsigned long long ts2 = __builtin_amdgcn_s_memtime();
 #endif
+    if constexpr (MASK_ONLY) {
+        // the mask as every later reader sees it: rounded to bf16 (pad keys are not stored)
+        const __amdgpu_buffer_rsrc_t rs_m = make_rsrc(p.Mk + (long)b * S * S, (long)S * S * 2);
+#pragma unroll
+        for (int t = 0; t < NJ; ++t) {
+            const int j = 16 * t + 4 * g;
+            f32x4v m = {0.f, 0.f, 0.f, 0.f};
+            if (j < S) {
+                const f32x4v b2v = *reinterpret_cast<const f32x4v*>(b2s + j);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m[r] = acc[t][r] * inv2 + b2v[r];
+            }
+            buf_store4(rs_m, (q_ok && j < S) ? (unsigned)((q_lane * S + j) * 2) : 0xFFFFFFFFu, pack4(m));
+        }
+        return;
+    }
     // ================= phase 3: per head  softmax(scale K_h Q_h^T + M^T),  O^T = V_h^T P^T =================
     constexpr int LDH = ld_rt(HDP), nks = HDP / 32, ndt = HDP / 16;
     static_assert(LDH * 2 == G::CPRH * 16, "phase-3 image stride");

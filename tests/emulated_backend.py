@@ -328,8 +328,14 @@ class EmulatedBackend:
         e = torch.exp(logits - mx)
         sm = e.sum(dim=-1, keepdim=True)
         lse.view(B, H, S).copy_((mx + torch.log(sm)).squeeze(-1))
-        P = (e * (1.0 / sm)).bfloat16().float()                              # P.V runs on bf16 probabilities
-        out.view(B, S, D).copy_((P @ vh).transpose(1, 2).reshape(B, S, D))
+        if S <= 224 and hd <= 64:
+            # attn16_fwd3_core_kernel (round 4; every stage of Base-224): the UN-normalised exp(x - max) in (0, 1] is what
+            # is rounded to bf16 for the P.V product, and 1 / sum scales the fp32 output tile
+            P = e.bfloat16().float()
+            out.view(B, S, D).copy_(((P @ vh) * (1.0 / sm)).transpose(1, 2).reshape(B, S, D))
+        else:
+            P = (e * (1.0 / sm)).bfloat16().float()                          # P.V runs on bf16 probabilities
+            out.view(B, S, D).copy_((P @ vh).transpose(1, 2).reshape(B, S, D))
 
     def attn16_bwd(self, q, k, v, out, dout, Mk, MkT, lse, delta, dq, dk, dv, dM, B, S, H, hd):
         D = H * hd
