@@ -475,9 +475,12 @@ inline bool fwd2_enabled() {
     static const int on = [] { const char* e = getenv("CALM_ATTN16_V2"); return (e && e[0] == '0') ? 0 : 1; }();
     return on != 0;
 }
-// CALM_ATTN16_V3=0: the head loop stays inside attn16_fwd2_kernel (A/B runs); default: mask kernel + per-head core kernel
+// CALM_ATTN16_V3=1: EXPERIMENTAL (round 4, off by default) — phases 1-2 as attn16_fwd2_kernel<.., MASK_ONLY> and the head
+// loop as the persistent per-(image, head) kernel of attention_bf16_fwd3.h.  Parity-tested (tests/test_attention16_gpu.py
+// runs it in a child process); at bs = 256 it is 3 % faster than the fused kernel at S = 224 and 3-20 % slower at the smaller
+// stages — DESIGN.md section 7 has the measurements that led there and what they say bounds the head loop.
 inline bool fwd3_enabled() {
-    static const int on = [] { const char* e = getenv("CALM_ATTN16_V3"); return (e && e[0] == '0') ? 0 : 1; }();
+    static const int on = [] { const char* e = getenv("CALM_ATTN16_V3"); return (e && e[0] == '1') ? 1 : 0; }();
     return on != 0;
 }
 
@@ -508,12 +511,14 @@ int launch_fwd16_t(const Attn16P& p, size_t lds, hipStream_t s) {
                     if (e2 != hipSuccess) return (int)e2;
                     hipLaunchKernelGGL((attn16_fwd2_kernel<NP, HDP, true>), dim3(p2.groups * p.B), dim3(64 * nw2), lds2, s, p2);
                     CALM_LAUNCH_CHECK();
-                    static const int stagger = [] { const char* e = getenv("CALM_ATTN16_STAGGER"); return e ? atoi(e) : 0; }();
-                    p2.kv_shared = stagger;                  // (the core kernel's start offset of the odd wave slots, x 64 cycles)
+                    // persistent: as many workgroups as the chip holds at once (a multiple of 8: one share per XCD)
+                    constexpr int nw3 = Fwd3Geo<NP, HDP>::NW;
+                    const int slots3 = 256 * Fwd3Geo<NP, HDP>::WG_PER_CU;
+                    const int grid3 = p.B < slots3 ? p.B : slots3;        // one image (all its heads) at a time per workgroup
                     if (p.S == 32 * NP)
-                        hipLaunchKernelGGL((attn16_fwd3_core_kernel<NP, HDP, true>), dim3(p.B * p.H), dim3(256), lds3, s, p2);
+                        hipLaunchKernelGGL((attn16_fwd3_core_kernel<NP, HDP, true>), dim3(grid3), dim3(64 * nw3), lds3, s, p2);
                     else
-                        hipLaunchKernelGGL((attn16_fwd3_core_kernel<NP, HDP, false>), dim3(p.B * p.H), dim3(256), lds3, s, p2);
+                        hipLaunchKernelGGL((attn16_fwd3_core_kernel<NP, HDP, false>), dim3(grid3), dim3(64 * nw3), lds3, s, p2);
                     CALM_LAUNCH_CHECK();
                     const int t32c = (p.S + 31) / 32;
                     hipLaunchKernelGGL(mask_transpose_kernel, dim3(t32c, t32c, p.B), dim3(256), 0, s, (const __bf16*)p.Mk, p.MkT, p.S);

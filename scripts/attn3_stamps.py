@@ -20,15 +20,15 @@ lse = torch.empty(B, H, S, device="cuda")
 for _ in range(3):
     be.attn16_fwd(q, k, v, w1, b1, s1, w2, b2, s2, out, R, hp, hg, Mk, MkT, lse, B, S, H, hd)
 torch.cuda.synchronize()
-st = lse[:, :, :9].reshape(-1, 9).cpu()
-order = st[:, 8].argsort()
-st = st[order]
-names = ["rt100MHz", "issued", "staged", "qk_done", "softmax_done", "pv_done", "end"]  # qk/softmax/pv: first tile PAIR of wave 0
-import statistics
-print("workgroups", st.shape[0])
-for lo, hi, tag in ((0, 512, "first round (ids 0..511)"), (1024, 2048, "middle"), (2560, 3072, "last")):
-    seg = st[lo:hi]
-    med = [float(seg[:, i].median()) for i in range(7)]
-    print(f"{tag:28s} " + " ".join(f"{n}={m:9.0f}" for n, m in zip(names, med)))
-    print(f"{'':28s} stage_wait={med[2]-med[1]:8.0f} qk={med[3]-med[2]:8.0f} softmax={med[4]-med[3]:8.0f} pv={med[5]-med[4]:8.0f} "
-          f"tile1={med[5]-med[2]:8.0f} all_tiles={med[6]-med[2]:8.0f} cycles/100MHz-tick={med[6]/max(med[0],1):6.2f}")
+rows = []  # first item of workgroup wg = image wg, head 0
+for wg in range(256):                                  # first item of workgroup wg (grid 256, B % 8 == 0): xcd = wg & 7, it0 = wg >> 3
+    pass
+    rows.append(lse[wg, 0, :9].cpu())
+st = torch.stack(rows)
+names = ["rt100MHz", "prologue", "qk_done", "softmax_done", "pv_done", "item_done", "end"]
+print("workgroups with stamps", st.shape[0])
+med = [float(st[:, i].median()) for i in range(7)]
+items = float(st[:, 7].median())
+print(" ".join(f"{n}={m:9.0f}" for n, m in zip(names, med)))
+print(f"first item: qk={med[2]-med[1]:8.0f} softmax={med[3]-med[2]:8.0f} pv={med[4]-med[3]:8.0f} barrier_wait={med[5]-med[4]:8.0f} item={med[5]-med[1]:8.0f}; "
+      f"items/wg={items:.0f} avg item={(med[6]-med[1])/items:8.0f} cycles; cycles per 100MHz tick={med[6]/max(med[0],1):6.2f}")

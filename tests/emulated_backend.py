@@ -6,6 +6,7 @@ the same argument meaning (strides, in-place outputs, accumulate semantics).  Tw
 It is never imported by the package.
 """
 import math
+import os
 
 import torch
 
@@ -328,9 +329,9 @@ class EmulatedBackend:
         e = torch.exp(logits - mx)
         sm = e.sum(dim=-1, keepdim=True)
         lse.view(B, H, S).copy_((mx + torch.log(sm)).squeeze(-1))
-        if S <= 224 and hd <= 64:
-            # attn16_fwd3_core_kernel (round 4; every stage of Base-224): the UN-normalised exp(x - max) in (0, 1] is what
-            # is rounded to bf16 for the P.V product, and 1 / sum scales the fp32 output tile
+        if os.environ.get("CALM_ATTN16_V3") == "1" and S <= 224 and hd <= 64:
+            # attn16_fwd3_core_kernel (round 4, experimental, opt-in): the UN-normalised exp(x - max) in (0, 1] is what is
+            # rounded to bf16 for the P.V product, and 1 / sum scales the fp32 output tile
             P = e.bfloat16().float()
             out.view(B, S, D).copy_(((P @ vh) * (1.0 / sm)).transpose(1, 2).reshape(B, S, D))
         else:

@@ -153,3 +153,16 @@ def test_attention16_eight_images_take_the_xcd_paired_order(S, H, hd):
     for n, a, b_ in (("dq", dq_h, dq_r), ("dk", dk_h, dk_r), ("dv", dv_h, dv_r), ("dM", dM_h, dM_r)):
         assert torch.isfinite(a.float()).all(), n
         assert rel_err(a.float(), b_.float()) < 1.2e-2, (n, rel_err(a.float(), b_.float()))
+
+
+def test_attention16_forward_v3_experimental_kernels_match_in_a_child_process():
+    """CALM_ATTN16_V3=1 (read once per process): mask kernel + persistent per-(image, head) core kernel
+    (csrc/attention_bf16_fwd3.h) against the emulation of ITS rounding points, on the four stage shapes of Base-224."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, CALM_ATTN16_V3="1")
+    nodes = [f"{os.path.abspath(__file__)}::test_attention16_forward_matches_emulation[{S}-{H}-{hd}]" for S, H, hd in SHAPES[:4]]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x"] + nodes,
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "4 passed" in r.stdout, r.stdout[-2000:] + r.stderr[-1000:]
