@@ -348,7 +348,7 @@ def main():
                          "bf16 operands (autocast arithmetic, configs #3-5), the fp32-accurate bf16x3 split, or fp8: "
                          "the bf16 pipeline with fp8 Linear forward / input-gradient GEMMs (config #5)")
     ap.add_argument("--prof-steps", type=int, default=1)
-    ap.add_argument("--graph", action="store_true", help="capture the whole step into a hipGraph (N=1 only)")
+    ap.add_argument("--graph", action="store_true", help="capture the whole step (with the RCCL all-reduces when N > 1) into a hipGraph")
     ap.add_argument("--torch-optim", action="store_true",
                     help="clip_grad_norm_ + torch.optim.AdamW(fused) instead of the library's 3-launch optimizer-side "
                          "step (calm_optim_step, which also folds in the spectral-norm gradient correction)")
@@ -385,13 +385,14 @@ def main():
         trainer.sync_module_states(model)
         x, y = synthetic_batch(batch, S, classes, seed=rank, device=device)     # resident in HBM before timing
         if args.graph:
-            if world > 1:
-                raise SystemExit("--graph is single-GPU only")
             opt = trainer.make_optimizer(model, capturable=True) if args.torch_optim else trainer.FusedClipAdamW(model)
             if autocast and precision != "fp8":
                 precision = "bf16"
+            # N > 1: the bucketed RCCL all-reduces are captured with the step (round 4: capture-compatible collectives,
+            # trainer.BucketedGradReducer._launch; verified in a world of one, tests/test_trainer_gpu.py)
+            reducer = trainer.BucketedGradReducer(model) if world > 1 else None
             step = trainer.GraphedTrainStep(model, opt, x, y, scaler=torch.amp.GradScaler("cuda") if autocast else None,
-                                            autocast_dtype=torch.bfloat16 if autocast else None)
+                                            autocast_dtype=torch.bfloat16 if autocast else None, reducer=reducer)
             prof_steps = 0                                 # events cannot be recorded inside a replayed graph
         else:
             opt = trainer.make_optimizer(model) if args.torch_optim else trainer.FusedClipAdamW(model)

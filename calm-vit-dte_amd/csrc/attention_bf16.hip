@@ -515,6 +515,9 @@ int launch_fwd16_t(const Attn16P& p, size_t lds, hipStream_t s) {
                     constexpr int nw3 = Fwd3Geo<NP, HDP>::NW;
                     const int slots3 = 256 * Fwd3Geo<NP, HDP>::WG_PER_CU;
                     const int grid3 = p.B < slots3 ? p.B : slots3;        // one image (all its heads) at a time per workgroup
+                    // start offset of the second wave of every SIMD, x 64 cycles (default: about half an item at S = 224)
+                    static const int stagger = [] { const char* e = getenv("CALM_ATTN16_STAGGER"); return e ? atoi(e) : 60; }();
+                    p2.kv_shared = stagger;
                     if (p.S == 32 * NP)
                         hipLaunchKernelGGL((attn16_fwd3_core_kernel<NP, HDP, true>), dim3(grid3), dim3(64 * nw3), lds3, s, p2);
                     else

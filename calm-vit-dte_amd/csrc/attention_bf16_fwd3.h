@@ -43,7 +43,7 @@ struct Fwd3Geo {
     static constexpr int SP = 32 * NP, NW = fwd3_waves(NP);
     static constexpr int CPRH = HDP / 8 + 2, NI3 = (SP * CPRH + 63) / 64;        // LDS-DMA instructions per image
     static constexpr int STAGE = 2 * NI3 * 1024;                                 // K_h and V_h images of one item
-    static constexpr int LDS = 2 * STAGE;                                        // two stages
+    static constexpr int LDS = 2 * STAGE + 64;                                   // two stages + the FULL / DONE words
     static constexpr int BY_LDS = (160 * 1024) / LDS, BY_WAVES = (NP <= 4 ? 12 : 8) / NW;     // (<= 256 VGPRs: two waves per SIMD; <= 168 below NP = 5: three)
     static constexpr int WG_PER_CU = BY_LDS < BY_WAVES ? BY_LDS : BY_WAVES;
     static constexpr bool OK = NP <= 7 && HDP <= 64 && WG_PER_CU >= 1;
@@ -153,6 +153,15 @@ __global__ __launch_bounds__(64 * fwd3_waves(NP), 2) void attn16_fwd3_core_kerne
     };
 
     if (n_it <= 0) return;
+    // Hand-off between the loader and the compute waves through two words per stage in LDS instead of workgroup barriers:
+    // FULL[s] = (item staged in s) + 1, written by the loader once its requests have landed; DONE[s] = number of
+    // (compute wave, item) passes that have finished with stage s.  With a barrier per item all compute waves of a
+    // workgroup ran their products, their softmax and their P V products at the same time — the matrix pipe idle while
+    // the two waves of a SIMD queue for its VALU and vice versa; without one, the start offset given to the second wave
+    // of every SIMD persists and one wave's softmax runs under the other's products.
+    volatile int* flags = reinterpret_cast<volatile int*>(smem3 + 2 * G::STAGE);
+    constexpr int NWC = NW - 1;
+    if (tid < 4) flags[tid] = 0;
     int b, h;
     item_bh(0, b, h);
     if (loader) {
@@ -213,27 +222,29 @@ __global__ __launch_bounds__(64 * fwd3_waves(NP), 2) void attn16_fwd3_core_kerne
                 }
             }
         };
-        stage_item(b, h, 0);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int stl = 0;
+        __builtin_amdgcn_s_barrier();                                  // (the FULL / DONE words are zero)
 #pragma unroll 1
-        for (int it = 0; it < n_it; ++it, stl ^= 1) {
-            const int itn = it + 1 < n_it ? it + 1 : it;               // (the last item re-stages itself: same barrier count)
-            int bn, hn;
-            item_bh(itn, bn, hn);
-            if (F3_ABLATE != 1) stage_item(bn, hn, stl ^ 1);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                              // publishes the other stage (compute waves: end of item)
+        for (int it = 0; it < n_it; ++it) {
+            const int sl = it & 1;
+            // the stage is free once every compute wave has finished the item that used it last (item it - 2)
+            while (flags[2 + sl] < NWC * (it >> 1)) __builtin_amdgcn_s_sleep(4);
+            asm volatile("" ::: "memory");
+            int bi, hi;
+            item_bh(it, bi, hi);
+            if (F3_ABLATE != 1 || it < 2) stage_item(bi, hi, sl);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the images have landed ...
+            flags[sl] = it + 1;                                            // ... publish: FULL[stage] = item + 1
         }
         return;
     }
     QIn qn;
     mu32x2 m0[NJ], m1[NJ];               // the pair's mask rows, for all heads of the image
     qn = request_q(b, h);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                                      // (the FULL / DONE words are zero)
     asm volatile("" ::: "memory");
+    // start offset of the second wave of every SIMD (waves 4 ..): p.kv_shared x 64 cycles, about half an item
+    if (wave >= 4)
+        for (int i = 0; i < p.kv_shared; i += 10) __builtin_amdgcn_s_sleep(10);
     F3_STAMP(1);
 
     const int q4 = c16 >> 2, p4 = c16 & 3;
@@ -246,6 +257,8 @@ __global__ __launch_bounds__(64 * fwd3_waves(NP), 2) void attn16_fwd3_core_kerne
         int bn, hn;
         item_bh(itn, bn, hn);
         {
+            while (flags[st] < it + 1) __builtin_amdgcn_s_sleep(2);        // the item's images are in stage st
+            asm volatile("" ::: "memory");
             const __bf16* imgK = reinterpret_cast<const __bf16*>(smem3 + st * G::STAGE);
             const __bf16* imgV = imgK + G::NI3 * 512;
             bf16x8 bq[QT][nks];
@@ -372,9 +385,10 @@ __global__ __launch_bounds__(64 * fwd3_waves(NP), 2) void attn16_fwd3_core_kerne
                 }
             }
             if (it == 0) F3_STAMP(4);
+            // done with the stage: every fragment read has returned (the products that use them have been issued)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (lane == 0) __hip_atomic_fetch_add(const_cast<int*>(flags) + 2 + st, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
-        __builtin_amdgcn_s_barrier();                      // publishes the other stage, frees this one
-        asm volatile("" ::: "memory");
         if (it == 0) F3_STAMP(5);
         b = bn;
         h = hn;

@@ -148,11 +148,20 @@ class BucketedGradReducer:
         op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
         if self.on_gpu:
             # the side stream starts after everything enqueued so far: the gradients exist, and the previous step's
-            # optimizer-side kernels (which read this bucket in place) have been issued before them
+            # optimizer-side kernels (which read this bucket in place) have been issued before them.  The collective is
+            # issued SYNCHRONOUSLY (async_op=False) on the side stream: for ProcessGroupNCCL that blocks nobody — it
+            # makes RCCL's stream wait for the side stream, enqueues the all-reduce there and makes the side stream wait
+            # for its end event — and it is the form that a stream capture supports (fork from the capturing stream by
+            # wait_stream, collectives on the fork with async_op=False, join by wait_stream: no Work object outlives
+            # the call, nothing is waited on from a non-captured stream; round 3 used async_op=True + work.wait() in
+            # finish() and ended in a segfault inside capture_end, gpurun_out/rccl.log)
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
                 torch._foreach_copy_(b["views"], grads)
-                work = dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True)
+                dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=False)
+                if not self.avg_in_collective:
+                    b["flat"].mul_(1.0 / self.world)
+            work = None
         else:
             torch._foreach_copy_(b["views"], grads)
             work = dist.all_reduce(b["flat"], op=op, group=self.pg, async_op=True)
@@ -170,12 +179,7 @@ class BucketedGradReducer:
                 self._launch(b)
         inv = 1.0 / self.world
         for work, b in self._works:
-            if self.on_gpu:
-                with torch.cuda.stream(self.side):
-                    work.wait()                     # side stream waits for RCCL; the host does not block
-                    if not self.avg_in_collective:
-                        b["flat"].mul_(inv)
-            else:
+            if work is not None:                    # CPU (gloo) path: asynchronous collectives, waited for here
                 work.wait()
                 if not self.avg_in_collective:
                     b["flat"].mul_(inv)
@@ -537,12 +541,16 @@ class GraphedTrainStep:
     that __call__ refreshes from param_groups[0]["lr"] before the replay; capturable torch optimizers keep theirs on
     the device already."""
 
-    def __init__(self, model, optimizer, example_x, example_y, max_norm=1.0, warmup=3, scaler=None, autocast_dtype=None):
-        if dist.is_initialized() and dist.get_world_size() > 1:
-            # the captured step contains no gradient exchange: replicas would silently train apart (ADVICE r3)
-            raise RuntimeError("GraphedTrainStep captures a single-GPU step (no gradient all-reduce inside the graph); "
-                               "with world_size > 1 use TrainStep + BucketedGradReducer")
-        self.inner = TrainStep(model, optimizer, None, max_norm=max_norm, scaler=scaler, autocast_dtype=autocast_dtype)
+    def __init__(self, model, optimizer, example_x, example_y, max_norm=1.0, warmup=3, scaler=None, autocast_dtype=None,
+                 reducer=None):
+        """reducer: a BucketedGradReducer whose bucket copies and RCCL all-reduces are captured with the step (round 4:
+        the collectives are issued in the capture-compatible form, see BucketedGradReducer._launch; exercised in a world
+        of one in a child process by scripts/rccl_capture_check.py — DESIGN.md section 6 records the outcome)."""
+        if reducer is None and dist.is_initialized() and dist.get_world_size() > 1:
+            # the captured step would contain no gradient exchange: replicas would silently train apart (ADVICE r3)
+            raise RuntimeError("GraphedTrainStep captures a single-GPU step unless it is given the BucketedGradReducer "
+                               "to capture with it; with world_size > 1 pass reducer=... or use TrainStep")
+        self.inner = TrainStep(model, optimizer, reducer, max_norm=max_norm, scaler=scaler, autocast_dtype=autocast_dtype)
         self.opt = optimizer
         if isinstance(optimizer, FusedClipAdamW):
             optimizer.lr_on_device = True          # replays read the learning rate from a device scalar
