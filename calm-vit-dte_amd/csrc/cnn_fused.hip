@@ -378,7 +378,7 @@ int calm_cnn_residual_bwd(const float* dy, const float* x, const float* w0, cons
     d.out[0] = g0; d.out[1] = gb0; d.out[2] = g2; d.out[3] = gb2; d.out[4] = g4; d.out[5] = gb4;
     d.begin[0] = 0; d.begin[1] = 3 * CH; d.begin[2] = 4 * CH; d.begin[3] = 13 * CH; d.begin[4] = 14 * CH;
     d.begin[5] = 17 * CH; d.begin[6] = CNN_PART_N; d.nseg = 6;
-    hipLaunchKernelGGL(calm_reduce_partials_kernel, dim3((CNN_PART_N + 63) / 64), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(calm_reduce_partials_kernel, dim3((CNN_PART_N + 63) / 64), dim3(CALM_RED_THREADS), 0, as_stream(stream),
                        partials, grid, CNN_PART_N, CNN_PART_STRIDE, d);
     CALM_LAUNCH_CHECK();
     return 0;

@@ -88,8 +88,8 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 // ---- fixed-order cross-workgroup reductions (ABI v7) -------------------------------------------------------------------
 // Sums that span workgroups (LayerNorm dw, RoPE d_inv_freq, bias column sums, the latent KL sum, the CNN tail's weight
 // gradients) are two-stage: workgroup g writes its partial row to partials[g * stride .. + n) (caller-provided scratch)
-// and this second launch adds the G rows in a fixed tree over g — four row lanes (g mod 4), each with two running sums
-// in increasing g, combined as (l0 + l1) + (l2 + l3) — and ADDS the result to the output.  No atomics: the result
+// and this second launch adds the G rows in a fixed tree over g — sixteen row lanes (g mod 16), each with four running sums
+// in increasing g, combined pairwise in a fixed order — and ADDS the result to the output.  No atomics: the result
 // repeats bit for bit.  (Rounds 1-3 left every workgroup with one fp32 atomic per output element, which made the
 // backward differ in the last bits from run to run.)  Up to six output tensors side by side in one partial row:
 // columns [begin[k], begin[k + 1]) go to out[k].
@@ -98,30 +98,44 @@ struct CalmReduceDst {
     int begin[7];
     int nseg;
 };
-static __global__ __launch_bounds__(256) void calm_reduce_partials_kernel(const float* __restrict__ part, int G, int n,
-                                                                         int stride, const CalmReduceDst dst) {
-    __shared__ float red[4][64];
+#define CALM_RED_THREADS 1024
+static __global__ __launch_bounds__(CALM_RED_THREADS) void calm_reduce_partials_kernel(const float* __restrict__ part, int G,
+                                                                                      int n, int stride,
+                                                                                      const CalmReduceDst dst) {
+    // 16 row lanes (waves) x 64 columns; a row lane owns g = rg, rg + 16, ... with FOUR running sums (g mod 64 picks the
+    // sum), i.e. four loads in flight per thread: the first form of this kernel (4 row lanes x 2 sums, 256 threads) took
+    // 19.5 us per call on average — G / 8 dependent L2 round trips — and, at 173 calls per step, 3.4 ms of the step
+    __shared__ float red[CALM_RED_THREADS / 64][64];
     const int lane = threadIdx.x & 63, rg = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + lane;
-    float s0 = 0.f, s1 = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     if (c < n) {
+        const float* p = part + c;
         int g = rg;
-        for (; g + 4 < G; g += 8) {                      // two loads in flight per thread
-            s0 += part[(long)g * stride + c];
-            s1 += part[(long)(g + 4) * stride + c];
+        for (; g + 48 < G; g += 64) {
+            a0 += p[(long)g * stride];
+            a1 += p[(long)(g + 16) * stride];
+            a2 += p[(long)(g + 32) * stride];
+            a3 += p[(long)(g + 48) * stride];
         }
-        if (g < G) s0 += part[(long)g * stride + c];
+        if (g < G) a0 += p[(long)g * stride];
+        if (g + 16 < G) a1 += p[(long)(g + 16) * stride];
+        if (g + 32 < G) a2 += p[(long)(g + 32) * stride];
     }
-    red[rg][lane] = s0 + s1;
+    red[rg][lane] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (rg == 0 && c < n) {
+        float t[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            t[q] = (red[4 * q][lane] + red[4 * q + 1][lane]) + (red[4 * q + 2][lane] + red[4 * q + 3][lane]);
         int k = 0;
         while (k + 1 < dst.nseg && c >= dst.begin[k + 1]) ++k;
-        dst.out[k][c - dst.begin[k]] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        dst.out[k][c - dst.begin[k]] += (t[0] + t[1]) + (t[2] + t[3]);
     }
 }
 static inline void calm_reduce_partials(const float* part, int G, int n, float* out, hipStream_t s) {
     CalmReduceDst d{};
     d.out[0] = out; d.begin[0] = 0; d.begin[1] = n; d.nseg = 1;
-    hipLaunchKernelGGL(calm_reduce_partials_kernel, dim3((n + 63) / 64), dim3(256), 0, s, part, G, n, n, d);
+    hipLaunchKernelGGL(calm_reduce_partials_kernel, dim3((n + 63) / 64), dim3(CALM_RED_THREADS), 0, s, part, G, n, n, d);
 }

@@ -863,7 +863,7 @@ static int rope_bwd_grid(long nrows, int dc, int dr) {
     // every workgroup ends with a row of dr/2 partials: few workgroups for small launches (A/B at S=80 with the
     // atomics of rounds 1-3: 1024 -> 25 us, 2048 -> 36, 4096 -> 60), ~16 row passes per workgroup for large ones
     const int want = gv / 16;
-    return want < CALM_ROPE_BWD_GRID ? (gv < CALM_ROPE_BWD_GRID ? gv : CALM_ROPE_BWD_GRID) : (want < 4096 ? want : 4096);
+    return want < CALM_ROPE_BWD_GRID ? (gv < CALM_ROPE_BWD_GRID ? gv : CALM_ROPE_BWD_GRID) : (want < 2048 ? want : 2048);
 }
 
 int calm_rope_bwd(const void* d_out, const void* xr, const float* table, void* d_content, void* d_xr,
