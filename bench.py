@@ -547,6 +547,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(out), flush=True)
     if world > 1:
+        import gc
+        gc.collect()                      # captured graphs (--graph) hold RCCL kernels: gone before the communicator
+        torch.cuda.synchronize()
         dist.destroy_process_group()
 
 

@@ -45,4 +45,11 @@ for graphed in (False, True):
 (l0, s0), (l1, s1) = res
 worst = max(rel_err(s1[k].float(), s0[k].float()) for k in s0)
 print("CAPTURE_OK", worst, l0, l1, flush=True)
+# orderly teardown: the captured graph holds RCCL kernels of this communicator — release it (and everything that
+# references it) BEFORE the process group goes away; one of four runs of the first version of this script, which
+# destroyed the group with the graph still alive, ended in SIGABRT after its work was done
+del step, red, opt, m
+import gc
+gc.collect()
+torch.cuda.synchronize()
 dist.destroy_process_group()

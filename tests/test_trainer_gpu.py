@@ -663,5 +663,12 @@ def test_graph_capture_of_the_step_with_the_rccl_all_reduces_inside_equals_eager
     script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "rccl_capture_check.py")
     r = subprocess.run([sys.executable, script], capture_output=True, text=True, timeout=600)
     ok = [ln for ln in r.stdout.splitlines() if ln.startswith("CAPTURE_OK")]
-    assert r.returncode == 0 and ok, (r.returncode, r.stdout[-1500:], r.stderr[-1500:])
+    try:                                                     # the child's own words, kept for the record whatever happens
+        out_dir = os.path.join(os.environ.get("GRAFT_REPO_ROOT", os.getcwd()), "gpurun_out")
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "rccl_capture_child.log"), "w") as f:
+            f.write(f"rc={r.returncode}\n--- stdout\n{r.stdout}\n--- stderr\n{r.stderr}\n")
+    except OSError:
+        pass
+    assert r.returncode == 0 and ok, (r.returncode, r.stdout[-1500:], r.stderr[-3000:])
     assert float(ok[0].split()[1]) < 1e-6, ok[0]
