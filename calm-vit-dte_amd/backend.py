@@ -206,13 +206,16 @@ class HipBackend:
     def __init__(self):
         self.lib = _lib.load()
         self._scratch_bufs = {}
+        self._scratch_need = {}
         self.upcast_launches = 0        # calm_gemm launches re-run on fp32 copies (CALM_E_LAYOUT with bf16 tensors)
 
     def _partials(self, op, rows, cols, device):
         """Device scratch for the fixed-order cross-workgroup reduction of one call (calm_reduce_scratch_floats).  One
         buffer per (device, stream), reused by every call on that stream: the launches of one stream run in order, so a
         call's rows of partials have been consumed by its own reduction pass before the next call writes any."""
-        need = int(self.lib.calm_reduce_scratch_floats(op, rows, cols))
+        need = self._scratch_need.get((op, rows, cols))
+        if need is None:                                         # (a step has ~170 such calls over ~20 distinct shapes)
+            need = self._scratch_need[(op, rows, cols)] = int(self.lib.calm_reduce_scratch_floats(op, rows, cols))
         key = (device.index, _stream())
         buf = self._scratch_bufs.get(key)
         if buf is None or buf.numel() < need:
