@@ -529,20 +529,25 @@ class FusedClipAdamW(torch.optim.Optimizer):
 
 class GraphedTrainStep:
     """The same step captured once into a hipGraph and replayed: every kernel of the library only enqueues on the
-    current stream (no allocation, no host sync), so forward + loss + backward + unscale / clip / AdamW is one graph
-    launch — with the library's fused optimizer-side step (FusedClipAdamW: its step counter and plan live on the
-    device) or a capturable torch optimizer, with or without the reference trainer's autocast(bfloat16) + GradScaler
-    (the scale update is device arithmetic, see TrainStep._finish).  Removes the ~3000 host-side launches per step: the
-    host's share of a step drops from tens of milliseconds to one graph launch, which is what keeps 8 ranks on one
-    host from becoming host-bound.  Single-GPU in this revision: capturing the bucketed RCCL all-reduce on its side stream
-    was tried in a world of one (torch 2.10 + RCCL 2.26.6) and crashes inside the capture, so N > 1 runs eagerly (the
-    constructor refuses a world of more than one rank).  Inputs are copied into static buffers.  A learning-rate
-    scheduler acts on replays: FusedClipAdamW reads the rate from a device scalar (calm_optim_step's lr_dev, ABI v7)
-    that __call__ refreshes from param_groups[0]["lr"] before the replay; capturable torch optimizers keep theirs on
-    the device already."""
+    current stream (no allocation, no host sync), so forward + loss + backward + gradient exchange + unscale / clip /
+    AdamW is one graph launch — with the library's fused optimizer-side step (FusedClipAdamW: its step counter, plan
+    and learning rate live on the device) or a capturable torch optimizer, with or without the reference trainer's
+    autocast(bfloat16) + GradScaler (the scale update is device arithmetic, see TrainStep._finish).  Removes the ~3000
+    host-side launches per step: the host's share of a step drops from tens of milliseconds to one graph launch, which
+    is what keeps 8 ranks on one host from becoming host-bound.  N > 1: pass the BucketedGradReducer — its bucket
+    copies and RCCL all-reduces are captured with the step (round 4; the collectives are issued in the
+    capture-compatible form, see BucketedGradReducer._launch); without one the constructor refuses a world of more than
+    one rank.  Inputs are copied into static buffers.  A learning-rate scheduler acts on replays: FusedClipAdamW reads
+    the rate from a device scalar (calm_optim_step's lr_dev, ABI v7) that __call__ refreshes from
+    param_groups[0]["lr"] before the replay; capturable torch optimizers keep theirs on the device already.
+
+    The warm-up steps in front of the capture (allocator, lazy plans) are real training steps on the example batch.
+    restore_after_warmup=True (FusedClipAdamW only) undoes them: parameters, buffers (spectral-norm u / v), optimizer
+    moments, the device step counter, the GradScaler state and the CUDA RNG state are put back IN PLACE after the
+    capture, so that the first replay is step 1 of the run — the replayed trajectory then equals the eager one."""
 
     def __init__(self, model, optimizer, example_x, example_y, max_norm=1.0, warmup=3, scaler=None, autocast_dtype=None,
-                 reducer=None):
+                 reducer=None, restore_after_warmup=False):
         """reducer: a BucketedGradReducer whose bucket copies and RCCL all-reduces are captured with the step (round 4:
         the collectives are issued in the capture-compatible form, see BucketedGradReducer._launch; exercised in a world
         of one in a child process by scripts/rccl_capture_check.py — DESIGN.md section 6 records the outcome)."""
@@ -556,6 +561,14 @@ class GraphedTrainStep:
             optimizer.lr_on_device = True          # replays read the learning rate from a device scalar
         self.x = example_x.clone()
         self.y = example_y.clone()
+        snap = None
+        if restore_after_warmup:
+            if not isinstance(optimizer, FusedClipAdamW):
+                raise ValueError("restore_after_warmup needs FusedClipAdamW (its whole state is a known set of tensors)")
+            live = list(model.parameters()) + list(model.buffers()) + optimizer.exp_avg + optimizer.exp_avg_sq + \
+                [optimizer._plan.step_dev]
+            snap = ([(t, t.detach().clone()) for t in live], torch.cuda.get_rng_state(example_x.device),
+                    None if scaler is None or not scaler.is_enabled() else scaler.get_scale())
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):                     # warm-up on a side stream (allocator + lazy plans)
@@ -566,6 +579,16 @@ class GraphedTrainStep:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss, self.y_hat = self.inner(self.x, self.y)
+        if snap is not None:                               # in place: the graph replays on these addresses
+            with torch.no_grad():
+                for t, c in snap[0]:
+                    t.copy_(c)
+            torch.cuda.set_rng_state(snap[1], example_x.device)
+            if snap[2] is not None:
+                scaler.update(new_scale=float(snap[2]))                # fill_ on the scale tensor the graph reads
+                if hasattr(self.inner, "_clean_steps"):
+                    self.inner._clean_steps.zero_()                    # (TrainStep._finish keeps the growth count itself)
+            torch.cuda.synchronize()
 
     def __call__(self, x, y_soft):
         self.x.copy_(x, non_blocking=True)
@@ -646,7 +669,7 @@ class SoftMixCollate:
 
 def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, epochs=15, batch_size=128,
           checkpoint_path=None, num_classes=1000, num_workers=0, collate_fn="mix", log_every=100, max_steps=None,
-          destroy_process_group=True, device_collate=False, crop=None):
+          destroy_process_group=True, device_collate=False, crop=None, graph=False):
     """Per-rank training job: the reference's `train(initializer, optimizer, scheduler, use_gpu, dataset, epochs,
     batch_size)` (distributed_trainer_cls.py:25-114) on torch.distributed + RCCL instead of Spark's TorchDistributor —
     start one process per GPU with `python -m torch.distributed.run --nproc-per-node N ...` (RANK / LOCAL_RANK /
@@ -672,7 +695,13 @@ def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, ep
     stacks them (default collate), the uint8 batch goes host-to-device as it is (a quarter of the fp32 bytes) and
     `DeviceCollate` does ToDtype + Normalize + RandomCrop(crop) + flip + CutMix / MixUp in one kernel pass, writing the
     first Block's row tokens [B,S,3S] directly — the model's first Block takes them without the image_to_rows pass
-    (cls:58-62,128-139; Vi_Tools:389-391)."""
+    (cls:58-62,128-139; Vi_Tools:389-391).
+
+    graph=True (GPU, optimizer "fused" / FusedClipAdamW): the step — forward, loss, backward, the bucketed RCCL
+    all-reduces of a world > 1, unscale / clip / AdamW — is captured into a hipGraph on the first batch
+    (GraphedTrainStep with restore_after_warmup: the capture's warm-up steps are undone) and replayed per batch: one
+    graph launch of host work per step instead of ~3000 kernel launches.  The DataLoader then drops the last partial
+    batch of an epoch (a graph has one batch shape); a batch of any other shape would run the eager step."""
     from torch.utils.data import DataLoader, DistributedSampler
     rank, local_rank, world = init_distributed(use_gpu)
     device = torch.device(f"cuda:{local_rank}" if use_gpu else "cpu")
@@ -700,13 +729,16 @@ def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, ep
         collate_fn = None                                   # default_collate: stack uint8 images and labels
     elif collate_fn == "mix":
         collate_fn = SoftMixCollate(num_classes=num_classes, seed=2006 + rank)
+    if graph and not (use_gpu and isinstance(optimizer, FusedClipAdamW)):
+        raise ValueError('graph=True needs use_gpu=True and optimizer="fused" (FusedClipAdamW)')
     loader = DataLoader(dataset, batch_size=batch_size, sampler=sampler, collate_fn=collate_fn, num_workers=num_workers,
-                        pin_memory=use_gpu, persistent_workers=num_workers > 0)
+                        pin_memory=use_gpu, persistent_workers=num_workers > 0, drop_last=bool(graph))
     scaler = torch.amp.GradScaler("cuda", enabled=use_gpu)                                                 # cls:64
     step = TrainStep(model, optimizer, reducer, max_norm=1.0, scaler=scaler if use_gpu else None,
                      autocast_dtype=torch.bfloat16 if use_gpu else None)
     model.train()
     n_steps = 0
+    gstep = None
     try:
         for epoch in range(epochs):
             sampler.set_epoch(epoch)
@@ -716,7 +748,13 @@ def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, ep
                 x, y = x.to(device, non_blocking=True), y.to(device, non_blocking=True)
                 if dcoll is not None:
                     x, y = dcoll(x, y.long(), crop=crop, tokens=True)   # uint8 batch -> row tokens + soft labels
-                loss, y_hat = step(x, y)
+                if graph and gstep is None:
+                    gstep = GraphedTrainStep(model, optimizer, x, y, max_norm=1.0, scaler=scaler,
+                                             autocast_dtype=torch.bfloat16, reducer=reducer, restore_after_warmup=True)
+                if gstep is not None and x.shape == gstep.x.shape and y.shape == gstep.y.shape:
+                    loss, y_hat = gstep(x, y)
+                else:
+                    loss, y_hat = step(x, y)
                 epoch_loss += loss.item()                                                                  # cls:97
                 if rank == 0 and local_rank == 0 and i % log_every == 0:
                     correct = (y_hat.reshape(y.shape[0], -1).argmax(1) == y.argmax(1)).sum().item()
@@ -733,6 +771,11 @@ def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, ep
             if max_steps is not None and n_steps >= max_steps:
                 break
     finally:
+        if gstep is not None:              # the captured graph holds RCCL kernels: released before the process group
+            gstep = None
+            import gc
+            gc.collect()
+            torch.cuda.synchronize()
         if isinstance(optimizer, FusedClipAdamW):
             optimizer.close()
     model = model.to("cpu")                                                                                # cls:112

@@ -262,6 +262,39 @@ def test_train_launcher_with_device_collate_consumes_uint8_batches():
     assert len(moved) > 50
 
 
+def test_train_launcher_graph_mode_replays_the_eager_trajectory():
+    """trainer.train(graph=True): the step (autocast + GradScaler + fused optimizer) is captured on the first batch and
+    replayed; the capture's warm-up steps are undone (GraphedTrainStep.restore_after_warmup: parameters, u / v buffers,
+    AdamW moments, device step counter, scale, RNG state), so four replayed steps leave exactly the model that four
+    eager steps leave (deterministic GEMM mode: no atomics anywhere in the step)."""
+    name = "tiny32_cls"
+    g = load_golden(name)
+    cfg = CONFIGS[name]
+    S = cfg.seq_length
+    gen = torch.Generator().manual_seed(3)
+    data = torch.utils.data.TensorDataset(torch.randn(16, 3, S, S, generator=gen),
+                                          torch.randint(0, cfg.out_features, (16,), generator=gen))
+    be = calm.backend.get_backend()
+    prev = be.gemm_set_option(be.GEMM_OPT_DETERMINISTIC, 1)
+    try:
+        outs = []
+        for graph in (False, True):
+            torch.manual_seed(11)
+            torch.cuda.manual_seed(11)
+            m = build_model(name, g, "cpu")
+            before = {k: v.clone() for k, v in m.state_dict().items()}
+            out = trainer.train(m, "fused", scheduler=None, use_gpu=True, dataset=data, epochs=2, batch_size=8,
+                                num_classes=cfg.out_features, log_every=1000, graph=graph)
+            outs.append({k: v.clone() for k, v in out.state_dict().items()})
+    finally:
+        be.gemm_set_option(be.GEMM_OPT_DETERMINISTIC, prev)
+    eager, replay = outs
+    moved = [k for k in eager if k.endswith("weight_orig") and not torch.equal(eager[k], before[k])]
+    assert len(moved) > 50                                   # both runs trained
+    worst = max(rel_err(replay[k].float(), eager[k].float()) for k in eager)
+    assert worst == 0.0, worst
+
+
 def test_gelu_module_and_bare_proj_are_callable_like_the_reference_sequential():
     """`GELU()(x)` and `block.proj(img)` (Vi_Tools:378-385: conv1x1 -> GELU -> dw3x3 -> GELU -> conv1x1, NO residual) called
     on their own, forward and backward against the emulation."""
