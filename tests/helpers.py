@@ -84,6 +84,16 @@ def oracle_params(name, golden=None, requires_grad=True):
     return P
 
 
+def rel_err_elem(a, b, floor=1e-2):
+    """Element-wise relative error with a magnitude floor: max |a - b| / max(|b|, floor * max|b|).  rel_err below is a
+    normalised inf-norm (an element 100x smaller than the tensor's largest may be off by 100 % at rel_err = 1e-2 ... );
+    this one bounds every element that is at least `floor` of the largest INDIVIDUALLY (VERDICT r3, weak #5)."""
+    a = torch.as_tensor(a, dtype=torch.float64).cpu()
+    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    scale = b.abs().max().clamp_min(1e-30)
+    return float(((a - b).abs() / torch.maximum(b.abs(), floor * scale)).max())
+
+
 def rel_err(a, b):
     a = torch.as_tensor(a, dtype=torch.float64).cpu()
     b = torch.as_tensor(b, dtype=torch.float64).cpu()

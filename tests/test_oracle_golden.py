@@ -6,7 +6,7 @@ import torch
 
 import weights as W
 from helpers import (BLOCK_FIXTURES, CONFIGS, REAL_SIZE_CFGS, block_fixture_params, block_shape, load_golden,
-                     load_inventory, oracle_params, rel_err)
+                     load_inventory, oracle_params, rel_err, rel_err_elem)
 from oracle import calm_oracle as O
 
 TOL = 1e-5
@@ -27,6 +27,7 @@ def test_eval_forward(name):
     with torch.no_grad():
         y, kl = O.vit_forward(P, cfg, x, training=False)
     assert rel_err(y, g["eval/y"]) < TOL
+    assert rel_err_elem(y, g["eval/y"]) < 100 * TOL           # element-wise, every element >= 1 % of the largest
     assert abs(float(kl) - float(g["eval/kl"])) <= TOL * max(1.0, abs(float(g["eval/kl"])))
     if name == "tiny32_cls":
         assert isinstance(kl, float) and kl == 0.0          # Vi_Tools:49-50 python 0.0
@@ -43,8 +44,10 @@ def test_train_forward_backward(name):
     loss = (y * gy).sum() + 0.5 * kl
     loss.backward()
     assert rel_err(y.detach(), g["train/y"]) < TOL
+    assert rel_err_elem(y.detach(), g["train/y"]) < 100 * TOL
     assert abs(float(kl) - float(g["train/kl"])) < TOL * max(1.0, abs(float(g["train/kl"])))
     assert rel_err(x.grad, g["train/dx"]) < 5 * TOL
+    assert rel_err_elem(x.grad, g["train/dx"]) < 500 * TOL
     names = [str(n) for n in g["train/grad_names"]]
     norms = g["train/grad_norms"]
     for n, ref in zip(names, norms):
