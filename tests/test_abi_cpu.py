@@ -57,12 +57,45 @@ def test_struct_layouts_match_the_header():
     sys.path.insert(0, ROOT)
     from importlib import import_module
     binding = import_module("calm_vit_dte_amd._lib")
-    src = '#include <stdio.h>\n#include "calm_vit.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(calm_gemm_args), ' \
-          'sizeof(calm_sn_layer), sizeof(calm_sn_plan_info), sizeof(calm_optim_tensor), sizeof(calm_optim_hparams));return 0;}\n'
+    src = '#include <stdio.h>\n#include "calm_vit.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(calm_gemm_args), ' \
+          'sizeof(calm_sn_layer), sizeof(calm_sn_plan_info), sizeof(calm_optim_tensor), sizeof(calm_optim_hparams), ' \
+          'sizeof(calm_gemm_plan));return 0;}\n'
     with tempfile.TemporaryDirectory() as d:
         c, exe = os.path.join(d, "s.c"), os.path.join(d, "s")
         open(c, "w").write(src)
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         sizes = [int(x) for x in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
-    mirrors = [binding.GemmArgs, binding.SnLayer, binding.SnPlanInfo, binding.OptimTensor, binding.OptimHparams]
+    mirrors = [binding.GemmArgs, binding.SnLayer, binding.SnPlanInfo, binding.OptimTensor, binding.OptimHparams, binding.GemmPlan]
     assert sizes == [ctypes.sizeof(m) for m in mirrors]
+
+
+def test_host_side_planning_entry_points_answer_without_a_gpu():
+    """The planning half of the C-ABI is host code (no launch, no device query): the scratch a reduction entry point
+    needs (calm_reduce_scratch_floats, ABI v7) and what a calm_gemm launch decomposes into (calm_gemm_describe).  The
+    pointers handed to describe are never dereferenced."""
+    sys.path.insert(0, ROOT)
+    from importlib import import_module
+    binding = import_module("calm_vit_dte_amd._lib")
+    lib = binding.load()
+    for op in (binding.RED_LAYERNORM_BWD, binding.RED_ROPE_BWD, binding.RED_LATENT_FWD, binding.RED_COLSUM, binding.RED_CNN_BWD):
+        for rows, cols in ((1, 4), (57344, 672), (20480, 240), (3, 1344)):
+            need = int(lib.calm_reduce_scratch_floats(op, rows, cols))
+            assert 0 < need <= (1 << 22), (op, rows, cols, need)          # a few MB at most: the backend keeps 4 MB per stream
+    assert int(lib.calm_reduce_scratch_floats(99, 10, 10)) == 0
+    g = binding.GemmArgs()
+    M, N, K = 57344, 1344, 672                                  # the bench's MLP forward on bf16 tensors
+    g.A, g.B, g.C = 0x10000, 0x20000, 0x30000
+    g.M, g.N, g.K = M, N, K
+    g.a_rs, g.a_cs, g.b_rs, g.b_cs, g.c_rs = K, 1, K, 1, N
+    g.batch0 = g.batch1 = 1
+    g.alpha = 1.0
+    g.dtype = 1
+    g.a_type = g.b_type = g.c_type = binding.ST_BF16
+    g.split_k = 1
+    plan = binding.GemmPlan()
+    assert lib.calm_gemm_describe(ctypes.byref(g), ctypes.byref(plan)) == 0
+    assert plan.family == 3 and plan.tile_k == 64 and plan.grid == 256 and plan.threads == 512
+    assert plan.tiles_m * plan.tile_m >= M and plan.tiles_n * plan.tile_n >= N and plan.items == plan.tiles_m * plan.tiles_n
+    g.dtype, g.a_type, g.b_type, g.c_type = 0, 0, 0, 0          # the same product on fp32 tensors: 128-row tiles
+    assert lib.calm_gemm_describe(ctypes.byref(g), ctypes.byref(plan)) == 0
+    assert plan.family == 0 and plan.tile_m == 128 and plan.tile_n in (96, 128)

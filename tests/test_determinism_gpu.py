@@ -40,12 +40,9 @@ def _busy(side, a, b):
             a.add_(1.0)
 
 
-def test_cross_workgroup_reductions_repeat_bit_for_bit():
-    """Each reduction entry point twice (the second time beside a memory-bound stream that perturbs workgroup timing):
-    identical bits; the sums themselves are checked against the emulation in test_kernels_gpu.py."""
-    be = calm.backend.get_backend()
-    side = torch.cuda.Stream()
-    a, b = torch.randn(16 << 20, device="cuda"), torch.empty(16 << 20, device="cuda")
+def _reduction_cases(be):
+    """One call of every entry point with a cross-workgroup reduction (ABI v7), at bench sizes and at ragged toy sizes
+    (vector and scalar kernels); each returns the tensors the call produced."""
 
     def ln(rows, D, g16):
         x, w, dy = rnd(rows, D, seed=1) * 2 + 0.5, 1 + 0.1 * rnd(D, seed=2), rnd(rows, D, seed=3)
@@ -98,7 +95,16 @@ def test_cross_workgroup_reductions_repeat_bit_for_bit():
              lambda: colsum(57344, 1344, True), lambda: colsum(4096, 448, False), lambda: colsum(500, 3, False),
              lambda: colsum(40, 1000, False), lambda: latent(20480, 240), lambda: latent(64, 24),
              lambda: cnn(32, 224), lambda: cnn(3, 36)]
-    for i, case in enumerate(cases):
+    return cases
+
+
+def test_cross_workgroup_reductions_repeat_bit_for_bit():
+    """Each reduction entry point twice (the second time beside a memory-bound stream that perturbs workgroup timing):
+    identical bits; the sums themselves are checked against the emulation in test_kernels_gpu.py."""
+    be = calm.backend.get_backend()
+    side = torch.cuda.Stream()
+    a, b = torch.randn(16 << 20, device="cuda"), torch.empty(16 << 20, device="cuda")
+    for i, case in enumerate(_reduction_cases(be)):
         ref = case()
         for rep in range(3):
             if rep:
@@ -106,6 +112,35 @@ def test_cross_workgroup_reductions_repeat_bit_for_bit():
             for got, want in zip(case(), ref):
                 assert torch.equal(got, want), (i, rep)
     torch.cuda.synchronize()
+
+
+def test_reduction_scratch_contract(monkeypatch):
+    """calm_reduce_scratch_floats(op, rows, cols) is the contract between caller and library for the `partials` argument
+    (include/calm_vit.h, ABI v7): with a buffer of EXACTLY that many floats every entry point produces the bits it
+    produces with the backend's large shared buffer, and it writes nothing behind the end (guard words intact)."""
+    be = calm.backend.get_backend()
+    guard, sentinel = 4096, 12345.0
+    made = []
+
+    def exact(op, rows, cols, device):
+        need = int(be.lib.calm_reduce_scratch_floats(op, rows, cols))
+        assert need > 0
+        buf = torch.full((need + guard,), sentinel, dtype=torch.float32, device=device)
+        made.append((buf, need))
+        return buf.data_ptr()
+
+    cases = _reduction_cases(be)
+    refs = [case() for case in cases]
+    monkeypatch.setattr(be, "_partials", exact)
+    for i, (case, ref) in enumerate(zip(cases, refs)):
+        made.clear()
+        got = case()
+        torch.cuda.synchronize()
+        assert made, i
+        for buf, need in made:
+            assert bool((buf[need:] == sentinel).all()), (i, need)
+        for g, w in zip(got, ref):
+            assert torch.equal(g, w), i
 
 
 def test_split_k_weight_gradient_is_reproducible_in_deterministic_mode(deterministic_gemm):
