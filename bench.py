@@ -381,6 +381,16 @@ def main():
         S, classes = wl["kw"]["seq_length"], wl["kw"]["out_features"]
         # under autocast the region selects the bf16 pipeline itself; a global 'fp8' adds the fp8 Linear products to it
         calm.backend.set_matmul_precision(("fp8" if precision == "fp8" else "fp32") if autocast else precision)
+        selfcheck = None
+        if autocast or precision in ("bf16", "fp8"):
+            # canary for the default bf16 GEMM family on THIS box (un-timed): a box on which the
+            # pipelined family disagrees with the 256x128 one runs the bench on the latter and says so in the line
+            sc = calm.backend.get_backend().selfcheck_bf16_gemm(on_mismatch="fallback")
+            selfcheck = {"ok": sc["ok"], "n_beyond_one_ulp": sum(c["n_bad"] for c in sc["cases"]),
+                         "n_one_ulp": sum(c["n_diff"] for c in sc["cases"]),
+                         "max_diff": max(c["max_diff"] for c in sc["cases"]),
+                         "family_used": "pipelined persistent (gemm_bf16p)" if sc["ok"] else "256x128 / 128-row (fallback)"}
+            torch.cuda.empty_cache()
         model = build_model(calm, wl["kw"], device).train()
         trainer.sync_module_states(model)
         x, y = synthetic_batch(batch, S, classes, seed=rank, device=device)     # resident in HBM before timing
@@ -427,7 +437,7 @@ def main():
             dt = float(t.item())
         res = {"workload": workload, "precision": precision, "batch": batch, "S": S, "wl": wl,
                "ms_per_step": 1e3 * dt / steps, "value": world * batch * steps / dt, "loss": float(loss),
-               "host_enqueue_ms": 1e3 * host / steps,
+               "host_enqueue_ms": 1e3 * host / steps, "selfcheck": selfcheck,
                "roofline": None, "attention": None}
 
         # dominant-kernel roofline: HIP events around every calm_gemm launch of prof_steps extra steps
@@ -517,7 +527,7 @@ def main():
                      "metric": "training images/sec (224^2, bs=256/GPU)", "value": round(r2["value"], 2), "unit": "images/sec",
                      "steps": 10, "warmup": 3, "ms_per_step": round(r2["ms_per_step"], 3), "dtype": PRECISION_INFO["bf16"][0],
                      "model_tflops": round(r2["value"] * r2["wl"]["gflop_img"] / 1e3, 2), "hbm_peak_gib": r2["hbm_peak_gib"],
-                     "host_enqueue_ms_per_step": round(r2["host_enqueue_ms"], 2),
+                     "host_enqueue_ms_per_step": round(r2["host_enqueue_ms"], 2), "gemm_family_selfcheck": r2["selfcheck"],
                      "roofline": r2["roofline"], "attention": r2["attention"]}
 
     if rank == 0:
@@ -538,6 +548,7 @@ def main():
             "model_tflops": round(value * wl["gflop_img"] / 1e3, 2),
             "hbm_peak_gib": main_res["hbm_peak_gib"],
             "host_enqueue_ms_per_step": round(main_res["host_enqueue_ms"], 2),
+            "gemm_family_selfcheck": main_res["selfcheck"],
             "roofline": roofline,
             "attention": attention if roofline is not None else None,
         }

@@ -234,6 +234,87 @@ class HipBackend:
             raise ValueError(f"calm_gemm_set_option({option}, {value}) -> {prev}")
         return prev
 
+    def selfcheck_bf16_gemm(self, rows=57344, on_mismatch="raise"):
+        """Canary for the default bf16 GEMM family: round 3 saw ONE box of the pool on which the
+        pipelined persistent family (gemm_bf16p_kernel: 128 KiB of LDS, 256 VGPRs, LDS-DMA) returned a deterministic
+        wrong GELU' input gradient at 57344 x 1344 x 1344 while the 256x128 family was right; the audit found no code
+        defect.  Until the cause is pinned, a training job can ask the box itself: this runs the three
+        operand-layout instantiations of the family at the bench's sizes — forward with fused bias + GELU (k-contiguous
+        pair), the GELU' input gradient (k-contiguous x row-contiguous) and a per-image product (row-contiguous pair) —
+        on both families and compares them (healthy boxes: identical up to a handful of results that sit on a bf16
+        rounding boundary — one ulp; a fault: more than one ulp AND more than 2^-9 of the largest element).  on_mismatch: "raise" (RuntimeError with the pattern of the differing elements), or "fallback"
+        (warn and switch this process to the 256x128 family — still the HIP path, 10-20 % slower GEMMs).
+        Returns {"ok", "cases": [{name, n_diff, n_bad, max_diff, plan, first}]}.  ~0.8 GB of scratch tensors, a few ms."""
+        import warnings
+        dev = torch.device("cuda", torch.cuda.current_device())
+        gen = torch.Generator(device="cpu").manual_seed(20061)
+        mk = lambda *shape, scale=1.0: (torch.randn(*shape, generator=gen) * scale).to(dev).bfloat16()
+        M, K, N = int(rows), 672, 1344
+        x, w1, dy, w2 = mk(M, K), mk(N, K, scale=K ** -0.5), mk(M, N), mk(N, N, scale=N ** -0.5)
+        bias = (torch.randn(N, generator=gen) * 0.1).to(dev)
+        sigma = torch.tensor([1.3], device=dev)
+        S, nb = 224, 64
+        pa, pb = mk(nb, S, S), mk(nb, S, 3 * S, scale=S ** -0.5)
+        hp = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+        e16 = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.bfloat16)
+        cases = [
+            ("forward bias+GELU (kk)", lambda out: ((x, w1, out, M, N, K, (K, 1, 0, 0), (K, 1, 0, 0), (N, 0, 0)),
+                                                    dict(inv_scale=sigma, bias=bias, act=ACT_GELU, C_pre=hp, split_k=1)), (M, N)),
+            ("GELU' input gradient (km)", lambda out: ((dy, w2, out, M, N, N, (N, 1, 0, 0), (1, N, 0, 0), (N, 0, 0)),
+                                                       dict(inv_scale=sigma, act=ACT_GELU_BWD, aux=hp, split_k=1)), (M, N)),
+            ("per-image product (mm)", lambda out: ((pa, pb, out, S, 3 * S, S, (1, S, S * S, 0), (1, 3 * S, S * 3 * S, 0),
+                                                     (3 * S, S * 3 * S, 0)), dict(batch=(nb, 1), split_k=1)), (nb, S, 3 * S)),
+        ]
+        prev_prec = get_matmul_precision()
+        set_matmul_precision("bf16")
+        report, ok = [], True
+        try:
+            for name, build, shape in cases:
+                got, alt = e16(*shape), e16(*shape)
+                args, kw = build(got)
+                plan = self.gemm_describe(*args, **kw)
+                self.gemm(*args, **kw)
+                prev = self.gemm_set_option(self.GEMM_OPT_PIPE, 0)
+                try:
+                    args2, kw2 = build(alt)
+                    self.gemm(*args2, **kw2)
+                finally:
+                    self.gemm_set_option(self.GEMM_OPT_PIPE, prev)
+                # the families accumulate k in different groupings, so a result that sits on a bf16 rounding boundary may
+                # land on either neighbour (measured: ~700 of 77 M elements of the GELU case, one ulp each); a fault is
+                # an element MORE than one bf16 ulp away AND off by more than 2^-9 of the largest element (the round-3
+                # box: 1.2e-2 of it; one stale 16-byte operand chunk: ~2e-2)
+                key = lambda t: torch.where(t.view(torch.int16) < 0, -(t.view(torch.int16).int() & 0x7FFF), t.view(torch.int16).int())
+                ulps = (key(got) - key(alt)).abs()
+                scale = float(alt.float().abs().max())
+                err = (got.float() - alt.float()).abs()
+                bad = (ulps > 1) & (err > 2.0 ** -9 * scale)
+                n_diff, n_bad = int((ulps > 0).sum()), int(bad.sum())
+                rec = {"name": name, "n_diff": n_diff, "n_bad": n_bad, "max_diff": float(err.max()) / max(scale, 1e-30),
+                       "plan": plan, "first": []}
+                if n_bad:
+                    idx = bad.reshape(-1, shape[-1]).nonzero()[:8].tolist()
+                    g2, a2 = got.reshape(-1, shape[-1]), alt.reshape(-1, shape[-1])
+                    rec["first"] = [(r, c, float(g2[r, c]), float(a2[r, c])) for r, c in idx]
+                    rec["rows"] = [int(bad.reshape(-1, shape[-1]).nonzero()[:, 0].min()), int(bad.reshape(-1, shape[-1]).nonzero()[:, 0].max())]
+                    if plan["family"] == 3:
+                        ok = False
+                report.append(rec)
+        finally:
+            set_matmul_precision(prev_prec)
+        res = {"ok": ok, "cases": report}
+        if not ok:
+            msg = ("the pipelined bf16 GEMM family disagrees with the 256x128 family on this box (see DESIGN.md section 2): " +
+                   "; ".join(f"{r['name']}: {r['n_bad']} elements beyond one ulp (rows {r.get('rows')}), max {r['max_diff']:.2e} "
+                             f"of the largest element, first (row, col, pipelined, 256x128) {r['first'][:3]}"
+                             for r in report if r["n_bad"]))
+            if on_mismatch == "fallback":
+                self.gemm_set_option(self.GEMM_OPT_PIPE, 0)
+                warnings.warn(msg + " -- continuing on the 256x128 family (calm_gemm_set_option(PIPE, 0))")
+            else:
+                raise RuntimeError(msg)
+        return res
+
     def gemm_describe(self, *args, **kw):
         """calm_gemm_describe (ABI v7) for the launch `gemm(*args, **kw)` would make: a dict of the plan's fields
         (family, tile, tiles, k-slices, items, grid ...).  Nothing is enqueued."""

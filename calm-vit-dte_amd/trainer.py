@@ -669,7 +669,7 @@ class SoftMixCollate:
 
 def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, epochs=15, batch_size=128,
           checkpoint_path=None, num_classes=1000, num_workers=0, collate_fn="mix", log_every=100, max_steps=None,
-          destroy_process_group=True, device_collate=False, crop=None, graph=False):
+          destroy_process_group=True, device_collate=False, crop=None, graph=False, selfcheck="raise"):
     """Per-rank training job: the reference's `train(initializer, optimizer, scheduler, use_gpu, dataset, epochs,
     batch_size)` (distributed_trainer_cls.py:25-114) on torch.distributed + RCCL instead of Spark's TorchDistributor —
     start one process per GPU with `python -m torch.distributed.run --nproc-per-node N ...` (RANK / LOCAL_RANK /
@@ -697,6 +697,11 @@ def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, ep
     first Block's row tokens [B,S,3S] directly — the model's first Block takes them without the image_to_rows pass
     (cls:58-62,128-139; Vi_Tools:389-391).
 
+    selfcheck ("raise" | "fallback" | None; GPU only, once per process): before the first step the box is asked whether
+    the two bf16 GEMM families agree on it (HipBackend.selfcheck_bf16_gemm — round 3 saw one box of the pool on which the
+    default pipelined family returned a deterministic wrong gradient); "raise" stops the job with the pattern of the
+    differing elements, "fallback" warns and trains on the 256x128 family.
+
     graph=True (GPU, optimizer "fused" / FusedClipAdamW): the step — forward, loss, backward, the bucketed RCCL
     all-reduces of a world > 1, unscale / clip / AdamW — is captured into a hipGraph on the first batch
     (GraphedTrainStep with restore_after_warmup: the capture's warm-up steps are undone) and replayed per batch: one
@@ -707,6 +712,13 @@ def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, ep
     device = torch.device(f"cuda:{local_rank}" if use_gpu else "cpu")
     if use_gpu:
         torch.cuda.set_device(device)
+    if use_gpu and selfcheck:
+        from .backend import get_backend
+        be = get_backend()
+        if not getattr(be, "_selfcheck_done", False):
+            be.selfcheck_bf16_gemm(on_mismatch=selfcheck)
+            be._selfcheck_done = True
+            torch.cuda.empty_cache()
     model = initializer.to(device)
     if optimizer == "fused":
         optimizer = FusedClipAdamW(model)

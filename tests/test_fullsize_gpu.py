@@ -198,3 +198,38 @@ def test_tokenisation_round_trips_at_bench_size():
     be.grid_transpose(t1, t2, B, S)
     assert torch.equal(t2, rows)                                           # involution, bit-exact
     assert torch.equal(t1, rows.view(B, S, S, 3).transpose(1, 2).reshape(B, S, 3 * S))
+
+
+def test_bf16_gemm_family_selfcheck_passes_and_detects_a_planted_fault(monkeypatch):
+    """HipBackend.selfcheck_bf16_gemm (the canary trainer.train() and bench.py run before a bf16-pipeline job): on this box
+    the pipelined family and the 256x128 family agree on its three bench-size launches up to one-ulp flips of results
+    on a bf16 rounding boundary; with a fault planted
+    (the pipelined launch's output perturbed in one 8-column chunk, the size of one stale 16-byte operand chunk) it raises,
+    or — on_mismatch="fallback" — switches the process to the other family."""
+    be = calm.backend.get_backend()
+    res = be.selfcheck_bf16_gemm()
+    assert res["ok"] and [c["plan"]["family"] for c in res["cases"]] == [3, 3, 3]
+    assert all(c["n_bad"] == 0 for c in res["cases"]), res
+    n_elems = 57344 * 1344
+    assert all(c["n_diff"] < 1e-4 * n_elems for c in res["cases"]), res       # rounding-boundary flips only (measured: ~700)
+    real = be.gemm
+
+    calls = {"n": 0}
+
+    def faulty(*args, **kw):
+        real(*args, **kw)
+        if kw.get("act") == calm.backend.ACT_GELU_BWD:              # the check runs each case twice: pipelined, then 256x128
+            if calls["n"] % 2 == 0:
+                args[2][1234, 256:264] += (0.05 * args[2].float().abs().max()).to(args[2].dtype)
+            calls["n"] += 1
+
+    monkeypatch.setattr(be, "gemm", faulty)
+    with pytest.raises(RuntimeError, match="disagrees"):
+        be.selfcheck_bf16_gemm()
+    prev = be.gemm_set_option(be.GEMM_OPT_PIPE, 1)
+    try:
+        with pytest.warns(UserWarning, match="256x128"):
+            assert not be.selfcheck_bf16_gemm(on_mismatch="fallback")["ok"]
+        assert be.gemm_set_option(be.GEMM_OPT_PIPE, 1) == 0          # it switched the family off
+    finally:
+        be.gemm_set_option(be.GEMM_OPT_PIPE, prev)
