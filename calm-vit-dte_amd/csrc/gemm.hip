@@ -34,6 +34,50 @@ __global__ __launch_bounds__(256) void splitk_reduce(const ReduceP q) {
     }
 }
 
+// The same on 16-byte vectors with four slices in flight (N, the output's row stride and the slice size multiples of 4,
+// 16-byte aligned bases): the scalar form above moved 3.2 TB/s of mostly cache-resident partial tiles (PMC, round 4:
+// 96 calls, 0.78 ms per fp32 step).  Fixed order: slice sl goes to running sum sl % 4, combined (s0 + s1) + (s2 + s3).
+__global__ __launch_bounds__(256) void splitk_reduce_vec(const ReduceP q) {
+    const long total4 = ((long)q.M * q.N) >> 2;
+    const f32x4* w = reinterpret_cast<const f32x4*>(q.ws + (long)blockIdx.y * q.nslices * q.ws_slice);
+    const long slice4 = q.ws_slice >> 2;
+    float* out = q.Cg[0] ? q.Cg[blockIdx.y] : q.C + blockIdx.y * q.c_b0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+        int sl = 0;
+        for (; sl + 3 < q.nslices; sl += 4) {
+            s0 += w[(long)sl * slice4 + i];
+            s1 += w[(long)(sl + 1) * slice4 + i];
+            s2 += w[(long)(sl + 2) * slice4 + i];
+            s3 += w[(long)(sl + 3) * slice4 + i];
+        }
+        if (sl < q.nslices) s0 += w[(long)sl * slice4 + i];
+        if (sl + 1 < q.nslices) s1 += w[(long)(sl + 1) * slice4 + i];
+        if (sl + 2 < q.nslices) s2 += w[(long)(sl + 2) * slice4 + i];
+        const unsigned e = (unsigned)(4 * i);
+        const unsigned m = e / (unsigned)q.N, n = e - m * (unsigned)q.N;
+        f32x4* dst = reinterpret_cast<f32x4*>(out + (long)m * q.c_rs + n);
+        const f32x4 sum = (s0 + s1) + (s2 + s3);
+        *dst = q.accumulate ? *dst + sum : sum;
+    }
+}
+
+static void launch_splitk_reduce(const ReduceP& q, int n_out, hipStream_t s) {
+    const long total = (long)q.M * q.N;
+    bool vec = (q.N & 3) == 0 && (q.c_rs & 3) == 0 && (q.c_b0 & 3) == 0 && (q.ws_slice & 3) == 0 && aligned16(q.ws) &&
+               total < (1l << 31);
+    for (int g = 0; g < 4; ++g) vec = vec && (!q.Cg[g] || aligned16(q.Cg[g]));
+    vec = vec && (q.Cg[0] || aligned16(q.C));
+    if (vec) {
+        const long t4 = total >> 2;
+        const int gx = (int)((t4 + 255) / 256 < 2048 ? (t4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce_vec, dim3(gx, n_out), dim3(256), 0, s, q);
+    } else {
+        const int gx = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+        hipLaunchKernelGGL(splitk_reduce, dim3(gx, n_out), dim3(256), 0, s, q);
+    }
+}
+
 inline bool mult4(int64_t x) { return (x & 3) == 0; }
 
 }  // namespace
@@ -217,9 +261,7 @@ static int pipe_run(const calm_gemm_args* a, GemmP& p, bool akc, bool bkc, bool 
     q.C = (float*)p.C; q.c_b0 = a->c_b0; q.c_rs = a->c_rs;
     for (int g = 0; g < 4; ++g) q.Cg[g] = p.slices_per_batch ? (float*)p.Cg[g] : nullptr;
     q.M = a->M; q.N = a->N; q.accumulate = a->accumulate;
-    const long total = (long)a->M * a->N;
-    const int gx = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(splitk_reduce, dim3(gx, n_out), dim3(256), 0, s, q);
+    launch_splitk_reduce(q, n_out, s);
     CALM_LAUNCH_CHECK();
     return 0;
 }
@@ -493,9 +535,7 @@ static int gemm_run(const calm_gemm_args* a, void* stream, int64_t* query, calm_
     q.C = (float*)p.C; q.c_b0 = a->c_b0; q.c_rs = a->c_rs;
     for (int g = 0; g < 4; ++g) q.Cg[g] = p.slices_per_batch ? (float*)p.Cg[g] : nullptr;
     q.M = a->M; q.N = a->N; q.accumulate = a->accumulate;
-    const long total = (long)a->M * a->N;
-    const int gx = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-    hipLaunchKernelGGL(splitk_reduce, dim3(gx, n_out), dim3(256), 0, s, q);
+    launch_splitk_reduce(q, n_out, s);
     CALM_LAUNCH_CHECK();
     return 0;
 }

@@ -63,6 +63,45 @@ __global__ __launch_bounds__(NT) void grid_transpose_kernel(const float* __restr
     }
 }
 
+// The same with 16-byte global accesses (S % 4 == 0: every row segment of a tile starts 16-byte aligned and its valid part
+// is a whole number of float4).  The scalar form above moves 3.3-3.4 TB/s (PMC, round 4) where the LayerNorm / RoPE / cast
+// kernels move 5-5.9: it issues one 4-byte access per element and a workgroup has 24 KB in flight.
+__global__ __launch_bounds__(NT) void grid_transpose_vec_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                                int S) {
+    __shared__ float tile[32][97];
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const float* src = in + (long)b * S * S * 3;
+    float* dst = out + (long)b * S * S * 3;
+    const int row_floats = 3 * S;
+#pragma unroll
+    for (int k = 0; k < (32 * 24) / NT; ++k) {
+        const int e = threadIdx.x + k * NT;
+        const int ii = e / 24, f = 4 * (e - ii * 24);
+        const int i = i0 + ii;
+        if (i < S && 3 * j0 + f < row_floats) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((long)i * S + j0) * 3 + f);
+            tile[ii][f] = v[0]; tile[ii][f + 1] = v[1]; tile[ii][f + 2] = v[2]; tile[ii][f + 3] = v[3];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < (32 * 24) / NT; ++k) {
+        const int e = threadIdx.x + k * NT;
+        const int jj = e / 24, f = 4 * (e - jj * 24);
+        const int j = j0 + jj;
+        if (j < S && 3 * i0 + f < row_floats) {
+            f32x4 o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ii = (f + q) / 3, c = (f + q) - 3 * ii;
+                o[q] = tile[ii][3 * jj + c];
+            }
+            *reinterpret_cast<f32x4*>(dst + ((long)j * S + i0) * 3 + f) = o;
+        }
+    }
+}
+
 // depthwise 3x3, channels-last [B,S,S,C]
 __global__ __launch_bounds__(NT) void dwconv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ inv_scale,
@@ -245,7 +284,11 @@ int calm_grid_transpose(const float* in, float* out, int32_t B, int32_t S, void*
     if (!in || !out || B <= 0 || S <= 0 || in == out) return CALM_E_INVAL;
     if (B > 65535) return CALM_E_UNSUPP;
     const int t = (S + 31) / 32;
-    hipLaunchKernelGGL(grid_transpose_kernel, dim3(t, t, B), dim3(NT), 0, as_stream(stream), in, out, S);
+    static_assert((32 * 24) % NT == 0, "vector tile map");
+    if ((S & 3) == 0 && aligned16(in) && aligned16(out))
+        hipLaunchKernelGGL(grid_transpose_vec_kernel, dim3(t, t, B), dim3(NT), 0, as_stream(stream), in, out, S);
+    else
+        hipLaunchKernelGGL(grid_transpose_kernel, dim3(t, t, B), dim3(NT), 0, as_stream(stream), in, out, S);
     CALM_LAUNCH_CHECK();
     return 0;
 }
