@@ -247,11 +247,11 @@ class HipBackend:
         Returns {"ok", "cases": [{name, n_diff, n_bad, max_diff, plan, first}]}.  ~0.8 GB of scratch tensors, a few ms."""
         import warnings
         dev = torch.device("cuda", torch.cuda.current_device())
-        gen = torch.Generator(device="cpu").manual_seed(20061)
-        mk = lambda *shape, scale=1.0: (torch.randn(*shape, generator=gen) * scale).to(dev).bfloat16()
+        gen = torch.Generator(device=dev).manual_seed(20061)           # (on the device: 250 M normals take seconds on the host)
+        mk = lambda *shape, scale=1.0: (torch.randn(*shape, generator=gen, device=dev) * scale).bfloat16()
         M, K, N = int(rows), 672, 1344
         x, w1, dy, w2 = mk(M, K), mk(N, K, scale=K ** -0.5), mk(M, N), mk(N, N, scale=N ** -0.5)
-        bias = (torch.randn(N, generator=gen) * 0.1).to(dev)
+        bias = torch.randn(N, generator=gen, device=dev) * 0.1
         sigma = torch.tensor([1.3], device=dev)
         S, nb = 224, 64
         pa, pb = mk(nb, S, S), mk(nb, S, 3 * S, scale=S ** -0.5)
