@@ -708,6 +708,10 @@ def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, ep
     graph launch of host work per step instead of ~3000 kernel launches.  The DataLoader then drops the last partial
     batch of an epoch (a graph has one batch shape); a batch of any other shape would run the eager step."""
     from torch.utils.data import DataLoader, DistributedSampler
+    if device_collate and not use_gpu:                     # (argument errors before any process group exists)
+        raise ValueError("device_collate=True needs use_gpu=True (the collate is a HIP kernel)")
+    if graph and not (use_gpu and (optimizer == "fused" or isinstance(optimizer, FusedClipAdamW))):
+        raise ValueError('graph=True needs use_gpu=True and optimizer="fused" (FusedClipAdamW)')
     rank, local_rank, world = init_distributed(use_gpu)
     device = torch.device(f"cuda:{local_rank}" if use_gpu else "cpu")
     if use_gpu:
@@ -741,8 +745,6 @@ def train(initializer, optimizer, scheduler=None, use_gpu=True, dataset=None, ep
         collate_fn = None                                   # default_collate: stack uint8 images and labels
     elif collate_fn == "mix":
         collate_fn = SoftMixCollate(num_classes=num_classes, seed=2006 + rank)
-    if graph and not (use_gpu and isinstance(optimizer, FusedClipAdamW)):
-        raise ValueError('graph=True needs use_gpu=True and optimizer="fused" (FusedClipAdamW)')
     loader = DataLoader(dataset, batch_size=batch_size, sampler=sampler, collate_fn=collate_fn, num_workers=num_workers,
                         pin_memory=use_gpu, persistent_workers=num_workers > 0, drop_last=bool(graph))
     scaler = torch.amp.GradScaler("cuda", enabled=use_gpu)                                                 # cls:64

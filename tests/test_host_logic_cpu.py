@@ -230,3 +230,21 @@ def test_bench_finds_its_kernels_in_the_committed_pmc_summaries():
         assert stale in (True, False)
     for f in glob.glob(os.path.join(root, "profiles", "round[2-9]_*pmc_summary.csv")):
         assert os.path.exists(f + ".stamp.json"), f
+
+
+def test_locate_inverts_the_kernels_xcd_aware_item_order():
+    """tests/locate.py::item_of_linear (used by the self-locating GEMM mismatch reports) must be the inverse of the item ->
+    linear-tile map of the persistent kernels (gemm_bf16p.h::decode: items with equal index mod 8 — one XCD — walk
+    consecutive tiles), for every item count: restated here from the kernel source and checked for bijectivity."""
+    from locate import item_of_linear
+
+    def lin_of_item(item, n_items):                     # gemm_bf16p.h:483-488
+        if n_items < 8:
+            return item
+        q, rem, x, idx = n_items >> 3, n_items & 7, item & 7, item >> 3
+        return (x * (q + 1) if x < rem else rem * (q + 1) + (x - rem) * q) + idx
+
+    for n in list(range(1, 70)) + [255, 256, 257, 528, 705, 1344, 4099]:
+        lins = [lin_of_item(i, n) for i in range(n)]
+        assert sorted(lins) == list(range(n)), n                      # the kernel's order is a permutation
+        assert all(item_of_linear(lins[i], n) == i for i in range(n)), n

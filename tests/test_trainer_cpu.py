@@ -188,3 +188,18 @@ def test_train_launcher_on_two_gloo_ranks(tmp_path, optimizer_kind):
     assert any(k.endswith("weight_orig") for k in ck)
     for k in ck:
         assert torch.equal(ck[k], r0["sd"][k])            # written after the last epoch's last step
+
+
+def test_graph_and_device_collate_options_refuse_cpu_runs_loudly():
+    """train(graph=True) / train(device_collate=True) are GPU features (a hipGraph of the step; the collate is a HIP
+    kernel): on a CPU run they raise before anything is built instead of silently training eagerly / on the host collate.
+    GraphedTrainStep refuses a world of more than one rank when it is not given the gradient reducer."""
+    data = torch.utils.data.TensorDataset(torch.randn(4, 3, 32, 32), torch.randint(0, 10, (4,)))
+    for kw in (dict(graph=True), dict(device_collate=True)):
+        with pytest.raises(ValueError):
+            trainer.train(torch.nn.Linear(4, 4), torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=0.1), use_gpu=False,
+                          dataset=data, epochs=1, batch_size=2, num_classes=10, destroy_process_group=True, **kw)
+    assert not torch.distributed.is_initialized()          # ... and before any process group was created
+    import inspect
+    src = inspect.getsource(trainer.GraphedTrainStep.__init__)
+    assert "get_world_size() > 1" in src and "raise RuntimeError" in src
