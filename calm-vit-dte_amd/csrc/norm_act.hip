@@ -364,12 +364,19 @@ struct RopePos {
     }
 };
 
-template <int VW>
+// TT: storage type of ALL tensors of the call as a compile-time constant (CALM_ST_F32 / CALM_ST_BF16), or -1 = per-tensor
+// run-time types.  With run-time types every load and store of the row loop sat behind its own scalar branch (ISA, round 4:
+// 20 branches per row, each access in its own basic block with its own wait): the accesses of a row could not overlap,
+// which is what held the bf16 calls (2-8 bytes per access) at 1.5-3.5 TB/s.  The model only ever mixes nothing.
+template <int TT> __device__ __forceinline__ int rope_type(int runtime_type) { return TT < 0 ? runtime_type : TT; }
+
+template <int VW, int TT>
 __global__ __launch_bounds__(NT) void rope_fwd_vec_kernel(const void* __restrict__ content, const void* __restrict__ xr,
                                                           const float* __restrict__ table, void* __restrict__ out,
-                                                          int nrows, int S, int H, int dc, int dr, int content_type,
-                                                          int xr_type, int out_type) {
+                                                          int nrows, int S, int H, int dc, int dr, int content_type_,
+                                                          int xr_type_, int out_type_) {
     typedef typename RopeVec<VW>::type vec;
+    const int content_type = rope_type<TT>(content_type_), xr_type = rope_type<TT>(xr_type_), out_type = rope_type<TT>(out_type_);
     const int half = dr >> 1, ir = half / VW, ic = dc / VW;             // rotation / content items per row
     const int rpb = NT / ir;                                            // rows per workgroup pass
     const int r_in = threadIdx.x / ir, j = threadIdx.x - r_in * ir;
@@ -394,13 +401,15 @@ __global__ __launch_bounds__(NT) void rope_fwd_vec_kernel(const void* __restrict
     }
 }
 
-template <int VW>
+template <int VW, int TT>
 __global__ __launch_bounds__(NT) void rope_bwd_vec_kernel(const void* __restrict__ d_out, const void* __restrict__ xr,
                                                           const float* __restrict__ table, void* __restrict__ d_content,
                                                           void* __restrict__ d_xr, float* __restrict__ dif_part,
-                                                          int nrows, int S, int H, int dc, int dr, int dout_type,
-                                                          int xr_type, int dcontent_type, int dxr_type) {
+                                                          int nrows, int S, int H, int dc, int dr, int dout_type_,
+                                                          int xr_type_, int dcontent_type_, int dxr_type_) {
     typedef typename RopeVec<VW>::type vec;
+    const int dout_type = rope_type<TT>(dout_type_), xr_type = rope_type<TT>(xr_type_),
+              dcontent_type = rope_type<TT>(dcontent_type_), dxr_type = rope_type<TT>(dxr_type_);
     __shared__ float facc[NT * VW];                    // [row lane][rotation pair]: rpb * half <= NT * VW floats
     const int half = dr >> 1, ir = half / VW, ic = dc / VW;
     const int rpb = NT / ir;
@@ -877,15 +886,22 @@ int calm_rope_fwd(const void* content, const void* xr, const float* inv_freq, fl
     const long nrows = (long)B * S * H;
     if (rope_vec_ok(nrows, dc, dr)) {
         const dim3 gv(rope_vec_grid(nrows, dc, dr));
-        if (rope_vw(dc, dr) == 4)
-            hipLaunchKernelGGL(rope_fwd_vec_kernel<4>, gv, dim3(NT), 0, as_stream(stream), content, xr, table, out,
-                               (int)nrows, S, H, dc, dr, content_type, xr_type, out_type);
-        else if (rope_vw(dc, dr) == 2)
-            hipLaunchKernelGGL(rope_fwd_vec_kernel<2>, gv, dim3(NT), 0, as_stream(stream), content, xr, table, out,
-                               (int)nrows, S, H, dc, dr, content_type, xr_type, out_type);
-        else
-            hipLaunchKernelGGL(rope_fwd_vec_kernel<1>, gv, dim3(NT), 0, as_stream(stream), content, xr, table, out,
-                               (int)nrows, S, H, dc, dr, content_type, xr_type, out_type);
+        const bool same = xr_type == out_type && (dc == 0 || content_type == out_type);
+        const int tt = !same ? -1 : out_type;
+#define ROPE_FWD(VWV, TTV)                                                                                              \
+    hipLaunchKernelGGL((rope_fwd_vec_kernel<VWV, TTV>), gv, dim3(NT), 0, as_stream(stream), content, xr, table, out,   \
+                       (int)nrows, S, H, dc, dr, content_type, xr_type, out_type)
+#define ROPE_FWD_T(VWV)                                                                                                 \
+    do {                                                                                                                \
+        if (tt == CALM_ST_BF16) ROPE_FWD(VWV, CALM_ST_BF16);                                                            \
+        else if (tt == CALM_ST_F32) ROPE_FWD(VWV, CALM_ST_F32);                                                         \
+        else ROPE_FWD(VWV, -1);                                                                                         \
+    } while (0)
+        if (rope_vw(dc, dr) == 4) ROPE_FWD_T(4);
+        else if (rope_vw(dc, dr) == 2) ROPE_FWD_T(2);
+        else ROPE_FWD_T(1);
+#undef ROPE_FWD_T
+#undef ROPE_FWD
         CALM_LAUNCH_CHECK();
         return 0;
     }
@@ -916,18 +932,22 @@ int calm_rope_bwd(const void* d_out, const void* xr, const float* table, void* d
     // kernel serves every shape of the path: dr/2 <= 256 rotation pairs, tensors below 2^31 elements)
     if (dr / 2 > ROPE_MAX_HALF || dr / 2 > NT || nrows * (dc + dr) >= (1L << 31)) return CALM_E_UNSUPP;
     const int gv = rope_bwd_grid(nrows, dc, dr);
-    if (rope_vw(dc, dr) == 4)
-        hipLaunchKernelGGL(rope_bwd_vec_kernel<4>, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table,
-                           d_content, d_xr, partials, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type,
-                           dxr_type);
-    else if (rope_vw(dc, dr) == 2)
-        hipLaunchKernelGGL(rope_bwd_vec_kernel<2>, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table,
-                           d_content, d_xr, partials, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type,
-                           dxr_type);
-    else
-        hipLaunchKernelGGL(rope_bwd_vec_kernel<1>, dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table,
-                           d_content, d_xr, partials, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type,
-                           dxr_type);
+    const bool same = xr_type == dout_type && dxr_type == dout_type && (dc == 0 || dcontent_type == dout_type);
+    const int tt = !same ? -1 : dout_type;
+#define ROPE_BWD(VWV, TTV)                                                                                              \
+    hipLaunchKernelGGL((rope_bwd_vec_kernel<VWV, TTV>), dim3(gv), dim3(NT), 0, as_stream(stream), d_out, xr, table,    \
+                       d_content, d_xr, partials, (int)nrows, S, H, dc, dr, dout_type, xr_type, dcontent_type, dxr_type)
+#define ROPE_BWD_T(VWV)                                                                                                 \
+    do {                                                                                                                \
+        if (tt == CALM_ST_BF16) ROPE_BWD(VWV, CALM_ST_BF16);                                                            \
+        else if (tt == CALM_ST_F32) ROPE_BWD(VWV, CALM_ST_F32);                                                         \
+        else ROPE_BWD(VWV, -1);                                                                                         \
+    } while (0)
+    if (rope_vw(dc, dr) == 4) ROPE_BWD_T(4);
+    else if (rope_vw(dc, dr) == 2) ROPE_BWD_T(2);
+    else ROPE_BWD_T(1);
+#undef ROPE_BWD_T
+#undef ROPE_BWD
     CALM_LAUNCH_CHECK();
     calm_reduce_partials(partials, gv, dr / 2, d_inv_freq, as_stream(stream));
     CALM_LAUNCH_CHECK();
