@@ -174,34 +174,35 @@ __global__ __launch_bounds__(NT) void ln_bwd_vec_kernel(const void* __restrict__
     }
     for (long row = wave; row < rows; row += nwaves) {
         const f32x4* xr = reinterpret_cast<const f32x4*>(x + row * D);
-        auto gr = [&](int c4) -> f32x4 {
-            if constexpr (G16) {
-                const bf16x4 g = reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(dy_) + row * D)[c4];
-                return (f32x4){(float)g[0], (float)g[1], (float)g[2], (float)g[3]};
-            } else {
-                return reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dy_) + row * D)[c4];
-            }
-        };
         const float mu = mean[row], rs = rstd[row];
         f32x4 xh[NV], gv[NV], av[NV];
         float c1 = 0.f, c2 = 0.f;
-        // the skip-connection gradient is requested together with x and dy: one memory latency per row, not a second
-        // one behind the two wave reductions
+        // Every load of the row is issued before anything is converted or masked: chunk indices past the row are CLAMPED
+        // (loaded, then zeroed by a select) instead of branched around, and bf16 gradients are converted after the last
+        // request — with the conversion inside a masked branch the compiler put `s_waitcnt vmcnt(0)` behind each of the NV
+        // gradient loads (ISA, round 4): three exposed round trips per row on top of the row's own, which is why the bf16
+        // variant moved 4.9 TB/s where the fp32 one moves 5.7.  The skip-connection gradient is requested together with x
+        // and dy: one memory latency per row, not a second one behind the two wave reductions.
         const f32x4* ar = dx_add ? reinterpret_cast<const f32x4*>(dx_add + row * D) : nullptr;
+        f32x4 xv[NV];
+        bf16x4 graw[G16 ? NV : 1];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int c4 = lane + 64 * i;
-            av[i] = (ar && c4 < nv4) ? ar[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
+            const int c4 = lane + 64 * i, cc = c4 < nv4 ? c4 : nv4 - 1;
+            xv[i] = xr[cc];
+            if constexpr (G16) graw[i] = reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(dy_) + row * D)[cc];
+            else gv[i] = reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(dy_) + row * D)[cc];
+            av[i] = ar ? ar[cc] : (f32x4){0.f, 0.f, 0.f, 0.f};
         }
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c4 = lane + 64 * i;
             const bool in = c4 < nv4;
-            const f32x4 xv = in ? xr[c4] : (f32x4){0.f, 0.f, 0.f, 0.f};
-            gv[i] = in ? gr(c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (G16) gv[i] = (f32x4){(float)graw[i][0], (float)graw[i][1], (float)graw[i][2], (float)graw[i][3]};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                xh[i][e] = in ? (xv[e] - mu) * rs : 0.f;
+                gv[i][e] = in ? gv[i][e] : 0.f;
+                xh[i][e] = in ? (xv[i][e] - mu) * rs : 0.f;
                 const float g = gv[i][e] * wv[i][e];
                 c1 += g; c2 += g * xh[i][e];
             }
