@@ -239,13 +239,23 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnFwdP p) {
         // Mk[b,i,j] is written once and re-read per head from L2 (NJ float4 per lane)
         if (active) {
             float* Mrow = p.Mk + ((long)b * p.Sq + iq) * p.Skv;
+            constexpr int BG = 4;                              // bias chunks requested four at a time (see attn_bwd_q_kernel)
 #pragma unroll
-            for (int t = 0; t < NJ; ++t) {
-                const f32x4v bb = *reinterpret_cast<const f32x4v*>(p.b2 + 16 * t + 4 * g);
-                f32x4v m;
+            for (int t0 = 0; t0 < NJ; t0 += BG) {
+                f32x4v bb[BG];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) m[r] = accM[t][r] * inv2 + bb[r];
-                *reinterpret_cast<f32x4v*>(Mrow + 16 * t + 4 * g) = m;
+                for (int u = 0; u < BG; ++u)
+                    if (t0 + u < NJ) bb[u] = *reinterpret_cast<const f32x4v*>(p.b2 + 16 * (t0 + u) + 4 * g);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < BG; ++u) {
+                    if (t0 + u < NJ) {
+                        f32x4v m;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) m[r] = accM[t0 + u][r] * inv2 + bb[u][r];
+                        *reinterpret_cast<f32x4v*>(Mrow + 16 * (t0 + u) + 4 * g) = m;
+                    }
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -499,24 +509,50 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_q_kernel(const AttnBwdP p) {
                 __syncthreads();
             }
         }
-        // delta, dS = P o (dP - delta); P is read twice (second time from L2) instead of being held in registers
+        // delta, dS = P o (dP - delta); P is read twice (second time from L2) instead of being held in registers.
+        // P and dS through __restrict__ locals: with the struct's plain pointers the compiler had to assume that the dS
+        // store of tile t may alias the P load of tile t + 1 and put `s_waitcnt vmcnt(0)` between them (ISA, round 4:
+        // 18-24 of the kernel's 26-35 global loads were followed by a full drain) — one exposed L2 round trip per key tile
+        // and head.
         const long prow = (((long)b * p.H + h) * p.Sq + (active ? iq : q0)) * p.Skv;
+        const float* __restrict__ Prow = p.P + prow + 4 * g;
+        float* __restrict__ dSrow = p.dS + prow + 4 * g;
+        // ... and in GROUPS of PG tiles requested together: left to itself the compiler reuses one register quad for all
+        // NJ loads of a loop — load, s_waitcnt vmcnt(0), use, eleven times over — i.e. 2 NJ exposed round trips per head
+        constexpr int PG = 4;
         float part = 0.f;
 #pragma unroll
-        for (int t = 0; t < NJ; ++t) {
-            const f32x4v pv = *reinterpret_cast<const f32x4v*>(p.P + prow + 16 * t + 4 * g);
+        for (int t0 = 0; t0 < NJ; t0 += PG) {
+            f32x4v pv[PG];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) part += pv[r] * accD[t][r];
+            for (int u = 0; u < PG; ++u)
+                if (t0 + u < NJ) pv[u] = *reinterpret_cast<const f32x4v*>(Prow + 16 * (t0 + u));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < PG; ++u)
+                if (t0 + u < NJ)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part += pv[u][r] * accD[t0 + u][r];
         }
         part += __shfl_xor(part, 16, 64);
         part += __shfl_xor(part, 32, 64);
 #pragma unroll
-        for (int t = 0; t < NJ; ++t) {
-            const f32x4v pv = *reinterpret_cast<const f32x4v*>(p.P + prow + 16 * t + 4 * g);
+        for (int t0 = 0; t0 < NJ; t0 += PG) {
+            f32x4v pv[PG];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) accD[t][r] = pv[r] * (accD[t][r] - part);
-            accM[t] = accM[t] + accD[t];
-            if (active) *reinterpret_cast<f32x4v*>(p.dS + prow + 16 * t + 4 * g) = accD[t];
+            for (int u = 0; u < PG; ++u)
+                if (t0 + u < NJ) pv[u] = *reinterpret_cast<const f32x4v*>(Prow + 16 * (t0 + u));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < PG; ++u) {
+                if (t0 + u < NJ) {
+                    const int t = t0 + u;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) accD[t][r] = pv[u][r] * (accD[t][r] - part);
+                    accM[t] = accM[t] + accD[t];
+                    if (active) *reinterpret_cast<f32x4v*>(dSrow + 16 * t) = accD[t];
+                }
+            }
         }
         // dQ^T[d,i] = scale * sum_j K_h[j,d] dS^T[j,i]
         if (active) {

@@ -74,14 +74,22 @@ __global__ __launch_bounds__(NT) void grid_transpose_vec_kernel(const float* __r
     const float* src = in + (long)b * S * S * 3;
     float* dst = out + (long)b * S * S * 3;
     const int row_floats = 3 * S;
+    constexpr int NLD = (32 * 24) / NT;
+    f32x4 v[NLD];
 #pragma unroll
-    for (int k = 0; k < (32 * 24) / NT; ++k) {
+    for (int k = 0; k < NLD; ++k) {                        // the three requests of a thread first, then the LDS writes
         const int e = threadIdx.x + k * NT;
         const int ii = e / 24, f = 4 * (e - ii * 24);
-        const int i = i0 + ii;
-        if (i < S && 3 * j0 + f < row_floats) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + ((long)i * S + j0) * 3 + f);
-            tile[ii][f] = v[0]; tile[ii][f + 1] = v[1]; tile[ii][f + 2] = v[2]; tile[ii][f + 3] = v[3];
+        const bool in = i0 + ii < S && 3 * j0 + f < row_floats;
+        const int ic = in ? i0 + ii : i0, fc = in ? f : 0;                  // (clamped: loaded, not stored)
+        v[k] = *reinterpret_cast<const f32x4*>(src + ((long)ic * S + j0) * 3 + fc);
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int e = threadIdx.x + k * NT;
+        const int ii = e / 24, f = 4 * (e - ii * 24);
+        if (i0 + ii < S && 3 * j0 + f < row_floats) {
+            tile[ii][f] = v[k][0]; tile[ii][f + 1] = v[k][1]; tile[ii][f + 2] = v[k][2]; tile[ii][f + 3] = v[k][3];
         }
     }
     __syncthreads();
