@@ -297,21 +297,31 @@ __global__ __launch_bounds__(64 * waves_for(NP), fwd_waves_per_simd(NP)) void at
         }
         // the mask as the backward will read it: rounded to bf16, -inf on the pad keys
         __bf16* Mrow = p.Mk + ((long)b * S + q_ld) * S;
+        // (the bias chunks are requested four at a time, clamped instead of branched: one at a time the compiler put
+        // `s_waitcnt vmcnt(0)` behind each of the NJ loads — ISA, round 4)
 #pragma unroll
-        for (int t = 0; t < NJ; ++t) {
-            const int j = 16 * t + 4 * g;
-            f32x4v m;
-            if (j < S) {
-                const f32x4v b2v = *reinterpret_cast<const f32x4v*>(p.b2 + j);
+        for (int t0 = 0; t0 < NJ; t0 += 4) {
+            f32x4v b2v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) m[r] = acc[t][r] * inv2 + b2v[r];
-            } else {
-                m = (f32x4v){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            for (int u = 0; u < 4; ++u) {
+                const int j = 16 * (t0 + u) + 4 * g;
+                if (t0 + u < NJ) b2v[u] = *reinterpret_cast<const f32x4v*>(p.b2 + (j < S ? j : 0));
             }
-            const bf16x4 m4 = pack4(m);
-            if (q_ok && j < S) *reinterpret_cast<bf16x4*>(Mrow + j) = m4;
-            acc[t] = unpack4(m4);
-            if (t & 1) Rf[t >> 1] = cat8(pack4(acc[t - 1]), m4);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + u;
+                if (t < NJ) {
+                    const int j = 16 * t + 4 * g;
+                    f32x4v m;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) m[r] = j < S ? acc[t][r] * inv2 + b2v[u][r] : -INFINITY;
+                    const bf16x4 m4 = pack4(m);
+                    if (q_ok && j < S) *reinterpret_cast<bf16x4*>(Mrow + j) = m4;
+                    acc[t] = unpack4(m4);
+                    if (t & 1) Rf[t >> 1] = cat8(pack4(acc[t - 1]), m4);
+                }
+            }
         }
         if constexpr (!KEEP_MASK) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // own mask stores before the re-reads
     }
