@@ -172,6 +172,10 @@ __global__ __launch_bounds__(64 * waves_for(NP), 2) void attn16_bwd2_kernel(cons
             part += __shfl_xor(part, 32, 64);
             delta = part;
             lse2 = lse_n * LOG2E;
+            // pinned here: left to the scheduler the multiply (and with it the wait for the lse load) sinks to its first
+            // use inside pair 0 — behind the first LDS-DMA requests of the next head, which the compiler's `vmcnt(0)` then
+            // drains as well (ISA, round 4: one exposed DMA round trip per head in the query-side kernel)
+            asm volatile("" : "+v"(delta), "+v"(lse2));
         }
         vm_wait_le(vm_seq - mark);
         if (edge_head(h)) edge_fixup(h);
